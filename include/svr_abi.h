@@ -1,0 +1,220 @@
+/*
+ * svr_abi.h -- C ABI of libsvr_hip.so, the MI355X (gfx950) drop-in for the render
+ * launch of sunwj/SunVolumeRender.
+ *
+ * Plain C: POD structs, plain pointers and sizes, no C++/torch types.  Two groups:
+ *
+ *  (A) The seven entry points of the reference's device layer, with the SAME symbol
+ *      names, so host code written against the reference (gui/canvas.cpp) links
+ *      unchanged.  In the reference they are `extern "C"` functions taking C++
+ *      references (pathtracer.h:17-24, raycasting.h:8); a reference is a pointer at
+ *      the ABI level, so the C prototypes below are binary-identical.  The POD
+ *      structs reproduce the reference classes byte for byte;
+ *      include/sunvolumerender/host_api.hpp gives C++ hosts the reference's class
+ *      names and methods over these layouts.
+ *
+ *  (B) svr_* helpers that stand in for the CUDA runtime calls the reference's HOST
+ *      code makes around that layer (texture objects, cudaMalloc of the HDR buffer,
+ *      device selection), plus documented extensions (render window for tile
+ *      sharding, multi-frame batches, counters, timing).  gfx950 has no texture
+ *      hardware exposed to HIP, so a "texture object" here is an opaque handle to a
+ *      software-sampler descriptor; it is carried in the same 64-bit field the
+ *      reference uses for cudaTextureObject_t.
+ *
+ * Error behaviour: the reference's functions return void and die through
+ * checkCudaErrors (utils/helper_cuda.h:966-977: print, cudaDeviceReset, exit).  The
+ * default here is the same (print to stderr, exit(EXIT_FAILURE)); with
+ * svr_set_error_mode(0) errors are recorded instead and readable through
+ * svr_last_error()/svr_last_error_code(), and svr_* functions return non-zero.
+ *
+ * Threading: like the reference (global __constant__ scene, pathtracer.cu:34-68) the
+ * scene is per-process, per-device state; calls are not re-entrant.
+ */
+#ifndef SVR_ABI_H
+#define SVR_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVR_MAX_LIGHT_SOURCES 8            /* common.h:11 */
+#define SVR_TF_TABLE_SIZE 1024             /* gui/transferfunction.h:29 */
+
+/* ---- POD layouts (all 4-byte floats; glm::vec3 is a packed 12-byte triple) ---- */
+typedef struct svr_vec2 { float x, y; } svr_vec2;
+typedef struct svr_vec3 { float x, y, z; } svr_vec3;
+
+typedef struct svr_bbox {                  /* cudaBBox, core/geometry/cuda_bbox.h:66-69; 36 B */
+    svr_vec3 vmin, vmax, invSize;
+} svr_bbox;
+
+typedef struct svr_volume {                /* cudaVolume, core/cuda_volume.h:111-121; 112 B, align 8 */
+    svr_bbox bbox;                         /*   0 */
+    uint32_t _pad0;                        /*  36 */
+    uint64_t tex;                          /*  40  handle from svr_create_volume_texture */
+    float densityScale;                    /*  48 */
+    float invMaxMagnitude;                 /*  52 */
+    float gradientFactor;                  /*  56 */
+    svr_vec3 spacing;                      /*  60 */
+    svr_vec3 invSpacing;                   /*  72 */
+    svr_vec2 x_clip, y_clip, z_clip;       /*  84, 92, 100 */
+    uint32_t _pad1;                        /* 108 */
+} svr_volume;
+
+typedef struct svr_transfer_function {     /* cudaTransferFunction, core/cuda_transfer_function.h:57-59; 16 B */
+    uint64_t tex;                          /* handle from svr_create_tf_texture */
+    float maxOpacity;                      /* Woodcock majorant */
+    uint32_t _pad;
+} svr_transfer_function;
+
+typedef struct svr_camera {                /* cudaCamera, core/cuda_camera.h:98-106; 76 B */
+    uint32_t imageW, imageH;
+    float exposure, apeture, focalLength, aspectRatio, tanFovxOverTwo;
+    svr_vec3 pos, u, v, w;
+} svr_camera;
+
+typedef struct svr_disk {                  /* cudaDisk, core/geometry/cuda_disk.h:58-61; 28 B */
+    float radius;
+    svr_vec3 center, normal;
+} svr_disk;
+
+typedef struct svr_area_light {            /* cudaAreaLight, core/lights/cuda_arealight.h:68-71; 44 B */
+    svr_disk disk;
+    svr_vec3 color;
+    float intensity;
+} svr_area_light;
+
+typedef struct svr_environment_light {     /* cudaEnvironmentLight, core/lights/cuda_environment_light.h:74-78; 32 B */
+    uint64_t tex;                          /* 0 = constant defaultRadiance; else handle from svr_create_env_texture */
+    svr_vec3 defaultRadiance;
+    float intensity;
+    svr_vec2 offset;
+} svr_environment_light;
+
+typedef struct svr_render_params {         /* RenderParams, core/render_parameters.h:34-37; 16 B */
+    uint32_t traceDepth;                   /* default 1 */
+    uint32_t frameNo;                      /* default 0 */
+    void* hdrBuffer;                       /* device pointer, W*H packed float3 (glm::vec3*) */
+} svr_render_params;
+
+/* =====================================================================
+ * (A) the reference's device-layer entry points (same symbol names)
+ * ===================================================================== */
+
+/* pathtracer.h:17 / pathtracer.cu:292-304.  One call = one sample per pixel: clears the
+ * accumulator iff frameNo==0, traces one path per pixel with seed wangHash(frameNo) +
+ * y*W + x, folds it into the running mean in hdrBuffer and tone-maps into img (device
+ * pointer, W*H RGBA8).  W,H come from the last setup_camera (the reference bakes 640x640,
+ * common.h:8-9).  Asynchronous on the launch stream, like the reference. */
+void render_pathtracer(void* img, const svr_render_params* renderParams);
+
+/* pathtracer.h:20-24 / pathtracer.cu:34-68: copy the POD into the per-device scene. */
+void setup_volume(const svr_volume* vol);
+void setup_transferfunction(const svr_transfer_function* tf);
+void setup_camera(const svr_camera* cam);
+void setup_env_lights(const svr_environment_light* light);
+void setup_area_lights(svr_area_light* lights, uint32_t n);   /* n is clamped to SVR_MAX_LIGHT_SOURCES */
+
+/* raycasting.h:8 / raycasting.cu:15-75: emission-absorption ray caster; scene passed by
+ * argument, not through the setup_* state, as in the reference. */
+void render_raycasting(void* img, svr_volume* volume, svr_transfer_function* transferFunction,
+                       svr_camera* camera, float stepSize);
+
+/* =====================================================================
+ * (B) helpers replacing the CUDA runtime calls of the reference's host code
+ * ===================================================================== */
+
+/* main.cpp:7-33 chooseBestDevice + cudaSetDevice: select the HIP device for this process. */
+int svr_init(int device);
+void svr_shutdown(void);
+/* launch stream for every kernel (a hipStream_t; NULL = the null stream).  Lets a host
+ * that owns streams (e.g. PyTorch) order the renderer with its own work. */
+int svr_set_stream(void* hip_stream);
+int svr_device_synchronize(void);                     /* canvas.cpp:106 cudaDeviceSynchronize */
+
+void svr_set_error_mode(int fatal);                   /* 1 (default): checkCudaErrors behaviour */
+const char* svr_last_error(void);
+int svr_last_error_code(void);
+void svr_clear_error(void);
+
+/* VolumeReader.cpp:138-172 (cudaMalloc3DArray + cudaMemcpy3D + cudaCreateTextureObject,
+ * border / linear / normalized-float / normalized coords): voxels is [nz][ny][nx] u16.
+ * src_is_device: voxels is a device pointer.  layout: SVR_LAYOUT_*.  Returns 0 on error. */
+#define SVR_LAYOUT_AUTO 0
+#define SVR_LAYOUT_LINEAR 1          /* [z][y][x] with a 2-voxel zero apron */
+#define SVR_LAYOUT_BRICK 2           /* 8x4x4-voxel bricks (256 B), 2-voxel zero apron */
+uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz,
+                                   int src_is_device, int layout);
+/* gui/transferfunction.cpp:30-44 (1D float4 array, clamp / linear / normalized coords). */
+uint64_t svr_create_tf_texture(const float* rgba, int n, int src_is_device);
+/* gui/transferfunction.cpp:128-176: re-upload after an edit (same n). */
+int svr_update_tf_texture(uint64_t handle, const float* rgba, int n, int src_is_device);
+/* core/lights/lights.cpp:41-74 (2D float4 array, wrap / linear / normalized coords). */
+uint64_t svr_create_env_texture(const float* rgba, int w, int h, int src_is_device);
+int svr_destroy_texture(uint64_t handle);             /* cudaDestroyTextureObject + cudaFreeArray */
+
+/* core/render_parameters.h:17-32: RenderParams::SetupHDRBuffer / Clear. */
+int svr_render_params_setup_hdr(svr_render_params* p, uint32_t w, uint32_t h);
+int svr_render_params_clear(svr_render_params* p);
+
+void* svr_device_malloc(size_t bytes);
+int svr_device_free(void* p);
+int svr_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes);
+int svr_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes);   /* canvas.cpp:100 */
+int svr_memset_device(void* dst_device, int value, size_t bytes);
+
+/* ---- documented extensions (not in the reference) ---- */
+
+/* Restrict render_pathtracer / render_raycasting to the rows y with
+ * (y / strip_rows) % world == rank (interleaved row strips; multi-GPU tile sharding).
+ * Seeds stay global (y*W+x), so the union over ranks is bit-identical to one GPU.
+ * strip_rows=0 or world<=1 resets to the full frame. */
+int svr_set_row_shard(uint32_t strip_rows, uint32_t rank, uint32_t world);
+/* Restrict to the pixel window [x0,x1) x [y0,y1) (combined with the row shard). Negative x1/y1 = full. */
+int svr_set_render_window(int x0, int y0, int x1, int y1);
+
+#define SVR_OPT_ENV_ON_ESCAPE 1   /* 1: add T*env(dir) when a path leaves the volume (the line the reference
+                                     comments out, pathtracer.cu:233).  default 0 = reference behaviour */
+#define SVR_OPT_KERNEL 2          /* 0 auto, 1 pixel-per-thread kernel, 2 persistent regenerating kernel */
+#define SVR_OPT_COUNT 3           /* 1: count volume taps etc. (slower; for roofline accounting) */
+#define SVR_OPT_TIMING 4          /* 1: bracket the path-tracing kernel with HIP events */
+#define SVR_OPT_SKIP_TONEMAP 5    /* 1: render_pathtracer does not run hdr_to_ldr (batch rendering) */
+#define SVR_OPT_BLOCKS_PER_CU 6   /* persistent kernel: workgroups per CU (0 = default) */
+int svr_set_option(int key, int value);
+int svr_get_option(int key);
+
+/* render_pathtracer for nframes consecutive frame numbers (renderParams->frameNo ...
+ * +nframes-1) in ONE launch; bit-identical to nframes calls, tone-maps once at the end. */
+int svr_render_pathtracer_frames(void* img, const svr_render_params* renderParams, uint32_t nframes);
+
+/* hdr_to_ldr alone (pathtracer.cu:282-290). */
+int svr_hdr_to_ldr(void* img, const svr_render_params* renderParams);
+
+typedef struct svr_counters {
+    uint64_t paths;
+    uint64_t vol_taps;         /* 8-voxel trilinear fetches */
+    uint64_t woodcock_iters;
+    uint64_t scatter_events;
+    uint64_t shadow_walks;
+    uint64_t raycast_steps;
+    uint64_t loop_iters;       /* persistent kernel: wave-level scheduler iterations */
+    uint64_t reserved;
+} svr_counters;
+int svr_get_counters(svr_counters* out);              /* synchronises the launch stream */
+int svr_reset_counters(void);
+
+/* accumulated HIP-event time of the path-tracing kernel since the last reset (SVR_OPT_TIMING) */
+int svr_get_kernel_time(double* total_ms, uint64_t* launches);
+int svr_reset_kernel_time(void);
+
+/* "name major.minor gcnArch CUs" of the active device, for logs */
+const char* svr_device_info(void);
+int svr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVR_ABI_H */

@@ -1,0 +1,178 @@
+"""ctypes binding of the CPU oracle (oracle/libsvr_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the
+sunvolumerender_amd package."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ORACLE_DIR = Path(__file__).resolve().parent
+LIB = ORACLE_DIR / "libsvr_oracle.so"
+
+
+class ovec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("paths", "vol_taps", "tf_taps", "rng_draws", "woodcock_iters",
+                                          "scatter_events", "shadow_walks", "raycast_steps")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def _scene_struct(abi):
+    """svo_scene, laid out with the product's ctypes PODs (they are byte-identical by contract)."""
+
+    class Scene(C.Structure):
+        _fields_ = [
+            ("vol", abi.cudaVolume),
+            ("tf", abi.cudaTransferFunction),
+            ("cam", abi.cudaCamera),
+            ("env", abi.cudaEnvironmentLight),
+            ("num_lights", C.c_uint32),
+            ("env_on_escape", C.c_uint32),
+            ("lights", abi.cudaAreaLight * 8),
+            ("vox", C.c_void_p),
+            ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+            ("tf_n", C.c_int32),
+            ("tf_rgba", C.c_void_p),
+            ("env_rgba", C.c_void_p),
+            ("env_w", C.c_int32), ("env_h", C.c_int32),
+        ]
+
+    return Scene
+
+
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    if force or not LIB.exists() or LIB.stat().st_mtime < (ORACLE_DIR / "svr_oracle.c").stat().st_mtime:
+        subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "libsvr_oracle.so"], check=True, capture_output=True)
+    return LIB
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB.exists():
+        build()
+    lib = C.CDLL(str(LIB))
+    F, U32, I = C.c_float, C.c_uint32, C.c_int
+    PF = C.POINTER(C.c_float)
+    lib.svo_wang_hash.restype, lib.svo_wang_hash.argtypes = U32, [U32]
+    lib.svo_xorwow_init.restype, lib.svo_xorwow_init.argtypes = None, [U32, C.POINTER(U32)]
+    lib.svo_xorwow_next.restype, lib.svo_xorwow_next.argtypes = U32, [C.POINTER(U32)]
+    lib.svo_xorwow_uniform.restype, lib.svo_xorwow_uniform.argtypes = F, [C.POINTER(U32)]
+    for name in ("svo_logf", "svo_expf", "svo_sinf", "svo_cosf", "svo_acosf"):
+        getattr(lib, name).restype = F
+        getattr(lib, name).argtypes = [F]
+    for name in ("svo_powf", "svo_atan2f"):
+        getattr(lib, name).restype = F
+        getattr(lib, name).argtypes = [F, F]
+    lib.svo_tex3d.restype, lib.svo_tex3d.argtypes = F, [C.c_void_p, F, F, F]
+    lib.svo_tex1d.restype, lib.svo_tex1d.argtypes = None, [C.c_void_p, F, PF]
+    lib.svo_tex2d.restype, lib.svo_tex2d.argtypes = None, [C.c_void_p, F, F, PF]
+    lib.svo_volume_intensity.restype, lib.svo_volume_intensity.argtypes = F, [C.c_void_p, PF]
+    lib.svo_volume_gradient.restype, lib.svo_volume_gradient.argtypes = None, [C.c_void_p, PF, PF]
+    lib.svo_volume_intersect.restype, lib.svo_volume_intersect.argtypes = I, [C.c_void_p, PF, PF, PF, PF]
+    lib.svo_camera_ray.restype, lib.svo_camera_ray.argtypes = None, [C.c_void_p, U32, U32, C.POINTER(U32), PF, PF]
+    lib.svo_camera_ray_pinhole.restype, lib.svo_camera_ray_pinhole.argtypes = None, [C.c_void_p, U32, U32, PF, PF]
+    lib.svo_disk_intersect.restype, lib.svo_disk_intersect.argtypes = I, [C.c_void_p, PF, PF, PF]
+    lib.svo_light_radiance.restype, lib.svo_light_radiance.argtypes = None, [C.c_void_p, PF]
+    lib.svo_schlick.restype, lib.svo_schlick.argtypes = F, [F, F, F]
+    lib.svo_microfacet_f.restype, lib.svo_microfacet_f.argtypes = F, [PF, PF, PF, F, F]
+    lib.svo_tonemap.restype, lib.svo_tonemap.argtypes = None, [PF, F, PF]
+    lib.svo_onb_from_w.restype, lib.svo_onb_from_w.argtypes = None, [PF, PF, PF]
+    lib.svo_render_pathtracer.restype = None
+    lib.svo_render_pathtracer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, U32, U32, I, I, I, I, C.c_void_p, I]
+    lib.svo_trace_path.restype = None
+    lib.svo_trace_path.argtypes = [C.c_void_p, U32, U32, U32, U32, PF, C.c_void_p]
+    lib.svo_hdr_to_ldr.restype, lib.svo_hdr_to_ldr.argtypes = None, [C.c_void_p, C.c_void_p, C.c_void_p, I, I, I, I]
+    lib.svo_render_raycasting.restype = None
+    lib.svo_render_raycasting.argtypes = [C.c_void_p, C.c_void_p, F, I, I, I, I, C.c_void_p, I]
+    lib.svo_max_threads.restype, lib.svo_max_threads.argtypes = I, []
+    lib.svo_sizeof.restype, lib.svo_sizeof.argtypes = I, [I]
+    _lib = lib
+    return lib
+
+
+class OracleScene:
+    """svo_scene built from a sunvolumerender_amd.scenes.Scene (plain data) -- the oracle's view of
+    exactly the inputs the HIP renderer gets."""
+
+    def __init__(self, scene):
+        from sunvolumerender_amd import abi, host
+
+        self.lib = load()
+        self.scene = scene
+        S = _scene_struct(abi)
+        assert C.sizeof(S) == self.lib.svo_sizeof(0), (C.sizeof(S), self.lib.svo_sizeof(0))
+        s = S()
+        nx, ny, nz = scene.dim
+        vol = host.create_device_volume(1, (nx, ny, nz), scene.spacing, scene.max_magnitude)
+        vol.densityScale = scene.density_scale
+        vol.gradientFactor = scene.gradient_factor
+        vol.x_clip = abi.vec2(*scene.clip[0])
+        vol.y_clip = abi.vec2(*scene.clip[1])
+        vol.z_clip = abi.vec2(*scene.clip[2])
+        s.vol = vol
+        s.tf.tex = 2
+        s.tf.maxOpacity = scene.max_opacity
+        s.cam = scene.resolved_camera()
+        env = host.env_light_constant(scene.env_radiance, scene.env_intensity)
+        env.offset = abi.vec2(*scene.env_offset)
+        self._vox = np.ascontiguousarray(scene.vox, dtype=np.uint16)
+        self._tf = np.ascontiguousarray(scene.tf_rgba, dtype=np.float32)
+        self._env = None
+        if scene.env_map is not None:
+            self._env = np.ascontiguousarray(scene.env_map, dtype=np.float32)
+            env.tex = 3
+            s.env_rgba = self._env.ctypes.data
+            s.env_h, s.env_w = self._env.shape[0], self._env.shape[1]
+        s.env = env
+        s.num_lights = len(scene.lights)
+        for i, l in enumerate(scene.lights):
+            s.lights[i] = l
+        s.env_on_escape = 1 if scene.env_on_escape else 0
+        s.vox = self._vox.ctypes.data
+        s.nx, s.ny, s.nz = nx, ny, nz
+        s.tf_n = self._tf.shape[0]
+        s.tf_rgba = self._tf.ctypes.data
+        self.s = s
+        self.W, self.H = scene.width, scene.height
+
+    @property
+    def ptr(self):
+        return C.addressof(self.s)
+
+    def new_hdr(self):
+        return np.zeros((self.H, self.W, 3), dtype=np.float32)
+
+    def render_pathtracer(self, hdr, frame_no, trace_depth=None, window=None, img=None, count=True, nthreads=0):
+        x0, y0, x1, y1 = window if window is not None else (0, 0, self.W, self.H)
+        c = Counters()
+        td = self.scene.trace_depth if trace_depth is None else trace_depth
+        self.lib.svo_render_pathtracer(self.ptr, hdr.ctypes.data, img.ctypes.data if img is not None else None,
+                                       td, frame_no, x0, y0, x1, y1, C.addressof(c) if count else None, nthreads)
+        return c.as_dict()
+
+    def render_raycasting(self, step_size=None, window=None, count=True, nthreads=0):
+        x0, y0, x1, y1 = window if window is not None else (0, 0, self.W, self.H)
+        img = np.zeros((self.H, self.W, 4), dtype=np.uint8)
+        c = Counters()
+        st = self.scene.step_size() if step_size is None else step_size
+        self.lib.svo_render_raycasting(self.ptr, img.ctypes.data, st, x0, y0, x1, y1, C.addressof(c) if count else None, nthreads)
+        return img, c.as_dict()
+
+    def hdr_to_ldr(self, hdr, window=None):
+        x0, y0, x1, y1 = window if window is not None else (0, 0, self.W, self.H)
+        img = np.zeros((self.H, self.W, 4), dtype=np.uint8)
+        self.lib.svo_hdr_to_ldr(self.ptr, hdr.ctypes.data, img.ctypes.data, x0, y0, x1, y1)
+        return img

@@ -1,0 +1,81 @@
+"""Build recipe for libsvr_hip.so (hipcc, gfx950 only) and for the CPU oracle.
+
+The numeric contract is part of the flags: no floating-point
+contraction, no fast-math, correctly rounded divide/sqrt.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_ROOT = PKG_DIR.parent
+CSRC = PKG_DIR / "csrc"
+LIB_DIR = PKG_DIR / "lib"
+LIB_PATH = LIB_DIR / "libsvr_hip.so"
+ORACLE_DIR = REPO_ROOT / "oracle"
+ORACLE_LIB = ORACLE_DIR / "libsvr_oracle.so"
+
+HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip"]
+HIP_HEADERS = ["svr_math.hpp", "svr_scene.hpp", "svr_device.hpp", "svr_kernels.hpp"]
+
+HIPCC_FLAGS = [
+    "-O3",
+    "--offload-arch=gfx950",
+    "-std=c++17",
+    "-fPIC",
+    "-shared",
+    "-ffp-contract=off",
+    "-fno-fast-math",
+    "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-Wall",
+    "-Wno-unused-value",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC=/path/to/hipcc)")
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP kernels + C-ABI into sunvolumerender_amd/lib/libsvr_hip.so."""
+    LIB_DIR.mkdir(exist_ok=True)
+    deps = [CSRC / f for f in HIP_SOURCES + HIP_HEADERS] + [REPO_ROOT / "include" / "svr_abi.h", Path(__file__)]
+    if not force and not _stale(LIB_PATH, deps):
+        return LIB_PATH
+    cmd = [_hipcc(), *HIPCC_FLAGS, *[str(CSRC / f) for f in HIP_SOURCES], "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    return LIB_PATH
+
+
+def build_oracle(force: bool = False) -> Path:
+    """Compile oracle/libsvr_oracle.so (test infrastructure; never loaded by the product)."""
+    deps = [ORACLE_DIR / "svr_oracle.c", ORACLE_DIR / "svr_oracle.h", ORACLE_DIR / "Makefile"]
+    if not force and not _stale(ORACLE_LIB, deps):
+        return ORACLE_LIB
+    res = subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "libsvr_oracle.so"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"oracle build failed:\n{res.stdout}\n{res.stderr}")
+    return ORACLE_LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv, verbose=True))
+    print(build_oracle(force="--force" in sys.argv))

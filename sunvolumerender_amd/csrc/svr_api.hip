@@ -1,0 +1,673 @@
+// svr_api.hip -- C-ABI layer of libsvr_hip.so (include/svr_abi.h).
+//
+// Holds what the reference keeps in __constant__ globals (pathtracer.cu:34-68) as a
+// per-process host-side scene, resolves the opaque texture handles into software-sampler
+// descriptors, and launches the gfx950 kernels.  No CPU rendering path exists here: every
+// entry point either launches HIP work or reports an error.
+#include "../../include/svr_abi.h"
+#include "svr_kernels.hpp"
+#include "svr_device.hpp"   // wang_hash (host)
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+static_assert(sizeof(svr_vec3) == 12, "glm::vec3 layout");
+static_assert(sizeof(svr_bbox) == 36, "cudaBBox layout");
+static_assert(sizeof(svr_volume) == 112 && offsetof(svr_volume, tex) == 40 && offsetof(svr_volume, densityScale) == 48 &&
+              offsetof(svr_volume, spacing) == 60 && offsetof(svr_volume, invSpacing) == 72 && offsetof(svr_volume, x_clip) == 84 &&
+              offsetof(svr_volume, z_clip) == 100, "cudaVolume layout");
+static_assert(sizeof(svr_transfer_function) == 16 && offsetof(svr_transfer_function, maxOpacity) == 8, "cudaTransferFunction layout");
+static_assert(sizeof(svr_camera) == 76 && offsetof(svr_camera, pos) == 28 && offsetof(svr_camera, w) == 64, "cudaCamera layout");
+static_assert(sizeof(svr_disk) == 28, "cudaDisk layout");
+static_assert(sizeof(svr_area_light) == 44 && offsetof(svr_area_light, color) == 28 && offsetof(svr_area_light, intensity) == 40, "cudaAreaLight layout");
+static_assert(sizeof(svr_environment_light) == 32 && offsetof(svr_environment_light, defaultRadiance) == 8 &&
+              offsetof(svr_environment_light, intensity) == 20 && offsetof(svr_environment_light, offset) == 24, "cudaEnvironmentLight layout");
+static_assert(sizeof(svr_render_params) == 16 && offsetof(svr_render_params, hdrBuffer) == 8, "RenderParams layout");
+static_assert(sizeof(svr_counters) == 8 * svr::CNT_N, "counter block");
+
+namespace {
+
+enum TexKind { TEX_VOLUME = 1, TEX_TF = 2, TEX_ENV = 3 };
+
+struct Texture {
+    uint32_t magic;
+    int kind;
+    void* data;          // device
+    int nx, ny, nz;      // volume dims / tf n / env w,h
+    int layout;
+    int sy, sz, bnx, bny;
+    size_t bytes;
+};
+constexpr uint32_t TEX_MAGIC = 0x53565254u;   // "SVRT"
+
+struct Context {
+    bool inited = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    std::string info;
+    // scene (the reference's __constant__ globals)
+    bool have_vol = false, have_tf = false, have_cam = false;
+    svr_volume vol{};
+    svr_transfer_function tf{};
+    svr_camera cam{};
+    svr_environment_light env{};
+    uint32_t num_lights = 0;
+    svr_area_light lights[SVR_MAX_LIGHT_SOURCES]{};
+    // options
+    int opt_env_on_escape = 0, opt_kernel = 0, opt_count = 0, opt_timing = 0, opt_skip_tonemap = 0, opt_blocks_per_cu = 0;
+    // sharding
+    uint32_t strip_rows = 0, rank = 0, world = 1;
+    int wx0 = 0, wy0 = 0, wx1 = -1, wy1 = -1;
+    // device scratch
+    unsigned long long* d_counters = nullptr;
+    uint32_t* d_ticket = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_pending = false;
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0;
+    // textures
+    std::unordered_map<uint64_t, Texture*> textures;
+    // errors
+    int fatal = 1;
+    int err_code = 0;
+    std::string err_msg;
+};
+
+Context g;
+std::mutex g_mu;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g.err_code = code ? code : -1;
+    g.err_msg = buf;
+    if (g.fatal) {
+        // utils/helper_cuda.h:966-977 behaviour: report and die
+        fprintf(stderr, "libsvr_hip error %d: %s\n", g.err_code, buf);
+        hipDeviceReset();
+        exit(EXIT_FAILURE);
+    }
+    return g.err_code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail((int)_e, "HIP error at %s:%d code=%d(%s) \"%s\"", __FILE__, __LINE__, \
+                        (int)_e, hipGetErrorName(_e), #expr);                              \
+    } while (0)
+
+int ensure_init()
+{
+    if (g.inited) return 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, "no HIP device available (hipGetDevice: %s)", hipGetErrorName(e));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    g.device = dev;
+    g.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s %d.%d %s CUs=%d", prop.name, prop.major, prop.minor, prop.gcnArchName, g.num_cus);
+    g.info = buf;
+    HIP_TRY(hipMalloc((void**)&g.d_counters, sizeof(svr_counters)));
+    HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
+    HIP_TRY(hipMalloc((void**)&g.d_ticket, 256));
+    HIP_TRY(hipMemset(g.d_ticket, 0, 256));
+    HIP_TRY(hipEventCreate(&g.ev0));
+    HIP_TRY(hipEventCreate(&g.ev1));
+    g.inited = true;
+    return 0;
+}
+
+Texture* find_tex(uint64_t h, int kind)
+{
+    auto it = g.textures.find(h);
+    if (it == g.textures.end()) return nullptr;
+    Texture* t = it->second;
+    if (t->magic != TEX_MAGIC || t->kind != kind) return nullptr;
+    return t;
+}
+
+bool finite3(const svr_vec3& v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); }
+
+// Build the device scene from the PODs.  All derived values use the same float operations, in
+// the same order, as the reference's device code would (they are part of the numeric contract).
+int build_scene(const svr_volume& vol, const svr_transfer_function& tf, const svr_camera& cam,
+                svr::DevScene& s)
+{
+    memset(&s, 0, sizeof s);
+    Texture* tv = find_tex(vol.tex, TEX_VOLUME);
+    if (!tv) return fail(-2, "cudaVolume.tex (0x%llx) is not a live volume texture handle", (unsigned long long)vol.tex);
+    Texture* tt = find_tex(tf.tex, TEX_TF);
+    if (!tt) return fail(-2, "cudaTransferFunction.tex (0x%llx) is not a live transfer-function handle", (unsigned long long)tf.tex);
+    if (!(tf.maxOpacity > 0.f) || !std::isfinite(tf.maxOpacity))
+        return fail(-3, "transfer function maxOpacity (Woodcock majorant) must be finite and > 0, got %g", (double)tf.maxOpacity);
+    if (!finite3(vol.bbox.vmin) || !finite3(vol.bbox.vmax) || !finite3(vol.bbox.invSize) || !finite3(vol.spacing) ||
+        !finite3(vol.invSpacing) || !std::isfinite(vol.densityScale))
+        return fail(-3, "cudaVolume has non-finite fields");
+    if (cam.imageW == 0 || cam.imageH == 0) return fail(-3, "camera image size is zero");
+
+    s.vmin[0] = vol.bbox.vmin.x; s.vmin[1] = vol.bbox.vmin.y; s.vmin[2] = vol.bbox.vmin.z;
+    s.invSize[0] = vol.bbox.invSize.x; s.invSize[1] = vol.bbox.invSize.y; s.invSize[2] = vol.bbox.invSize.z;
+    // cuda_bbox.h:38-39
+    s.clip_vmin[0] = vol.bbox.vmin.x * (-vol.x_clip.x);
+    s.clip_vmin[1] = vol.bbox.vmin.y * (-vol.y_clip.x);
+    s.clip_vmin[2] = vol.bbox.vmin.z * (-vol.z_clip.x);
+    s.clip_vmax[0] = vol.bbox.vmax.x * vol.x_clip.y;
+    s.clip_vmax[1] = vol.bbox.vmax.y * vol.y_clip.y;
+    s.clip_vmax[2] = vol.bbox.vmax.z * vol.z_clip.y;
+    s.densityScale = vol.densityScale;
+    s.invMaxMagnitude = vol.invMaxMagnitude;
+    s.gradientFactor = vol.gradientFactor;
+    {
+        volatile float c = -25.f * vol.gradientFactor;     // pathtracer.cu:251, left to right
+        c = c * vol.gradientFactor;
+        c = c * vol.gradientFactor;
+        s.pbrdf_c = c;
+    }
+    s.spacing[0] = vol.spacing.x; s.spacing[1] = vol.spacing.y; s.spacing[2] = vol.spacing.z;
+    s.invSpacing[0] = vol.invSpacing.x; s.invSpacing[1] = vol.invSpacing.y; s.invSpacing[2] = vol.invSpacing.z;
+    s.vox = (const uint16_t*)tv->data;
+    s.nx = tv->nx; s.ny = tv->ny; s.nz = tv->nz;
+    s.layout = tv->layout;
+    s.fnx = (float)tv->nx; s.fny = (float)tv->ny; s.fnz = (float)tv->nz;
+    s.sy = tv->sy; s.sz = tv->sz; s.bnx = tv->bnx; s.bny = tv->bny;
+
+    s.tf = (const float*)tt->data;
+    s.tf_n = tt->nx;
+    s.tf_nf = (float)tt->nx;
+    s.sigmaMax = tf.maxOpacity;
+    {
+        volatile float a = 1.f / tf.maxOpacity;            // woodcock_tracking.h:30
+        volatile float b = tf.maxOpacity * 1.f;            // BASE_SAMPLE_STEP_SIZE 1.f, :18
+        volatile float c2 = 1.f / b;                       // :31
+        s.invSigmaMax = a;
+        s.invSigmaMaxSI = c2;
+    }
+
+    s.imageW = cam.imageW; s.imageH = cam.imageH;
+    s.exposure = cam.exposure; s.apeture = cam.apeture; s.focalLength = cam.focalLength;
+    s.aspectRatio = cam.aspectRatio; s.tanFovxOverTwo = cam.tanFovxOverTwo;
+    s.wm1 = (float)cam.imageW - 1.f;
+    s.hm1 = (float)cam.imageH - 1.f;
+    s.cam_pos[0] = cam.pos.x; s.cam_pos[1] = cam.pos.y; s.cam_pos[2] = cam.pos.z;
+    s.cam_u[0] = cam.u.x; s.cam_u[1] = cam.u.y; s.cam_u[2] = cam.u.z;
+    s.cam_v[0] = cam.v.x; s.cam_v[1] = cam.v.y; s.cam_v[2] = cam.v.z;
+    s.cam_w[0] = cam.w.x; s.cam_w[1] = cam.w.y; s.cam_w[2] = cam.w.z;
+    return 0;
+}
+
+int add_lights_env(svr::DevScene& s)
+{
+    s.env = nullptr;
+    if (g.env.tex != 0) {
+        Texture* te = find_tex(g.env.tex, TEX_ENV);
+        if (!te) return fail(-2, "cudaEnvironmentLight.tex (0x%llx) is not a live environment texture handle", (unsigned long long)g.env.tex);
+        s.env = (const float*)te->data;
+        s.env_w = te->nx; s.env_h = te->ny;
+    }
+    s.env_default[0] = g.env.defaultRadiance.x; s.env_default[1] = g.env.defaultRadiance.y; s.env_default[2] = g.env.defaultRadiance.z;
+    s.env_intensity = g.env.intensity;
+    s.env_offset[0] = g.env.offset.x; s.env_offset[1] = g.env.offset.y;
+    s.env_on_escape = (uint32_t)g.opt_env_on_escape;
+    s.num_lights = g.num_lights;
+    for (uint32_t i = 0; i < g.num_lights; ++i) {
+        const svr_area_light& l = g.lights[i];
+        svr::DevLight& d = s.lights[i];
+        d.radius = l.disk.radius;
+        d.center[0] = l.disk.center.x; d.center[1] = l.disk.center.y; d.center[2] = l.disk.center.z;
+        d.normal[0] = l.disk.normal.x; d.normal[1] = l.disk.normal.y; d.normal[2] = l.disk.normal.z;
+        // cuda_disk.h:53-56: M_PI * radius * radius (double) -> float
+        volatile float area = (float)(3.14159265358979323846 * (double)l.disk.radius * (double)l.disk.radius);
+        d.area = area;
+        // cuda_arealight.h:57: 500.f * color * intensity * float(M_1_PI) / area, left to right per component
+        const float c3[3] = {l.color.x, l.color.y, l.color.z};
+        for (int c = 0; c < 3; ++c) {
+            volatile float r = 500.f * c3[c];
+            r = r * l.intensity;
+            r = r * (float)0.31830988618379067154;
+            r = r / area;
+            d.radiance[c] = r;
+        }
+    }
+    return 0;
+}
+
+int fill_work(svr::DevWork& w, uint32_t W, uint32_t H)
+{
+    memset(&w, 0, sizeof w);
+    w.counters = g.d_counters;
+    w.ticket = g.d_ticket;
+    w.strip_rows = g.strip_rows ? g.strip_rows : 1;
+    w.rank = g.rank;
+    w.world = g.world;
+    if (g.world > 1) {
+        // interleaved strips over the full frame
+        w.x0 = 0; w.x1 = W; w.y0 = 0; w.y1 = H;
+        uint32_t rows = 0;
+        uint32_t nstrips = (H + w.strip_rows - 1) / w.strip_rows;
+        for (uint32_t sidx = g.rank; sidx < nstrips; sidx += g.world) {
+            uint32_t ys = sidx * w.strip_rows;
+            uint32_t ye = ys + w.strip_rows < H ? ys + w.strip_rows : H;
+            rows += ye - ys;
+        }
+        // the strip->row formula in the kernels needs whole strips except possibly the last owned one
+        w.n_rows = rows;
+    } else {
+        int x0 = g.wx0 < 0 ? 0 : g.wx0, y0 = g.wy0 < 0 ? 0 : g.wy0;
+        int x1 = (g.wx1 < 0 || g.wx1 > (int)W) ? (int)W : g.wx1;
+        int y1 = (g.wy1 < 0 || g.wy1 > (int)H) ? (int)H : g.wy1;
+        if (x0 > x1) x0 = x1;
+        if (y0 > y1) y0 = y1;
+        w.x0 = (uint32_t)x0; w.x1 = (uint32_t)x1; w.y0 = (uint32_t)y0; w.y1 = (uint32_t)y1;
+        w.n_rows = w.y1 - w.y0;
+    }
+    w.n_items = w.n_rows * (w.x1 - w.x0);
+    return 0;
+}
+
+void collect_timing()
+{
+    if (g.ev_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g.ev1) == hipSuccess && hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) {
+            g.kernel_ms += (double)ms;
+            g.kernel_launches += 1;
+        }
+        g.ev_pending = false;
+    }
+}
+
+int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool tonemap)
+{
+    if (ensure_init()) return g.err_code;
+    if (!rp) return fail(-4, "render_pathtracer: renderParams is null");
+    if (!g.have_vol || !g.have_tf || !g.have_cam)
+        return fail(-4, "render_pathtracer before setup_volume/setup_transferfunction/setup_camera");
+    if (!rp->hdrBuffer) return fail(-4, "render_pathtracer: renderParams.hdrBuffer is null (call SetupHDRBuffer)");
+    if (nframes == 0) return 0;
+    svr::DevScene s;
+    if (build_scene(g.vol, g.tf, g.cam, s)) return g.err_code;
+    if (add_lights_env(s)) return g.err_code;
+    svr::DevWork w;
+    fill_work(w, s.imageW, s.imageH);
+    w.hdr = (float*)rp->hdrBuffer;
+    w.img = (uint8_t*)img;
+    w.traceDepth = rp->traceDepth;
+    w.frame0 = rp->frameNo;
+    w.nframes = nframes;
+    svr::LaunchCfg cfg;
+    cfg.kernel = g.opt_kernel == svr::KERNEL_AUTO ? svr::KERNEL_PERSISTENT : g.opt_kernel;
+    cfg.count = g.opt_count != 0;
+    cfg.num_cus = g.num_cus;
+    cfg.blocks_per_cu = g.opt_blocks_per_cu > 0 ? g.opt_blocks_per_cu : 4;
+    if (g.opt_timing) {
+        collect_timing();
+        HIP_TRY(hipEventRecord(g.ev0, g.stream));
+    }
+    HIP_TRY(svr::launch_pathtrace(s, w, cfg, g.stream));
+    if (g.opt_timing) {
+        HIP_TRY(hipEventRecord(g.ev1, g.stream));
+        g.ev_pending = true;
+    }
+    if (tonemap && img && !g.opt_skip_tonemap) HIP_TRY(svr::launch_tonemap(s, w, g.stream));
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int svr_abi_version(void) { return 1; }
+
+int svr_init(int device)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g.inited && g.device == device) return 0;
+    if (g.inited) return fail(-5, "svr_init(%d): already initialised on device %d (one scene per process, like the reference)", device, g.device);
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail((int)e, "hipSetDevice(%d) failed: %s", device, hipGetErrorName(e));
+    return ensure_init();
+}
+
+void svr_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.inited) return;
+    hipDeviceSynchronize();
+    for (auto& kv : g.textures) {
+        if (kv.second->data) hipFree(kv.second->data);
+        delete kv.second;
+    }
+    g.textures.clear();
+    if (g.d_counters) hipFree(g.d_counters);
+    if (g.d_ticket) hipFree(g.d_ticket);
+    if (g.ev0) hipEventDestroy(g.ev0);
+    if (g.ev1) hipEventDestroy(g.ev1);
+    int fatal = g.fatal;
+    g = Context();
+    g.fatal = fatal;
+}
+
+int svr_set_stream(void* hip_stream)
+{
+    if (ensure_init()) return g.err_code;
+    collect_timing();
+    g.stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+int svr_device_synchronize(void)
+{
+    if (ensure_init()) return g.err_code;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+void svr_set_error_mode(int fatal) { g.fatal = fatal ? 1 : 0; }
+const char* svr_last_error(void) { return g.err_msg.c_str(); }
+int svr_last_error_code(void) { return g.err_code; }
+void svr_clear_error(void) { g.err_code = 0; g.err_msg.clear(); }
+const char* svr_device_info(void) { ensure_init(); return g.info.c_str(); }
+
+// ---------------- textures ----------------
+uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz, int src_is_device, int layout)
+{
+    if (ensure_init()) return 0;
+    if (!voxels || nx <= 0 || ny <= 0 || nz <= 0) { fail(-6, "svr_create_volume_texture: bad arguments (%p, %d, %d, %d)", (const void*)voxels, nx, ny, nz); return 0; }
+    if (layout == SVR_LAYOUT_AUTO) layout = SVR_LAYOUT_LINEAR;
+    if (layout != SVR_LAYOUT_LINEAR && layout != SVR_LAYOUT_BRICK) { fail(-6, "svr_create_volume_texture: unknown layout %d", layout); return 0; }
+    Texture* t = new Texture();
+    t->magic = TEX_MAGIC; t->kind = TEX_VOLUME; t->nx = nx; t->ny = ny; t->nz = nz; t->layout = layout;
+    size_t px = (size_t)nx + 2 * svr::VOL_PAD, py = (size_t)ny + 2 * svr::VOL_PAD, pz = (size_t)nz + 2 * svr::VOL_PAD;
+    size_t elems;
+    if (layout == SVR_LAYOUT_LINEAR) {
+        t->sy = (int)px; t->sz = (int)(px * py); t->bnx = 0; t->bny = 0;
+        elems = px * py * pz;
+    } else {
+        size_t bx = (px + svr::BRICK_X - 1) / svr::BRICK_X, by = (py + svr::BRICK_Y - 1) / svr::BRICK_Y, bz = (pz + svr::BRICK_Z - 1) / svr::BRICK_Z;
+        t->bnx = (int)bx; t->bny = (int)by; t->sy = 0; t->sz = 0;
+        elems = bx * by * bz * (size_t)(svr::BRICK_X * svr::BRICK_Y * svr::BRICK_Z);
+    }
+    if (elems >= ((size_t)1 << 31)) { delete t; fail(-6, "svr_create_volume_texture: %zu padded voxels exceed 32-bit element indexing", elems); return 0; }
+    t->bytes = elems * sizeof(uint16_t);
+    size_t src_bytes = (size_t)nx * ny * nz * sizeof(uint16_t);
+    const uint16_t* d_src = voxels;
+    uint16_t* staged = nullptr;
+    hipError_t e;
+    if (!src_is_device) {
+        e = hipMalloc((void**)&staged, src_bytes);
+        if (e == hipSuccess) e = hipMemcpy(staged, voxels, src_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { if (staged) hipFree(staged); delete t; fail((int)e, "volume upload failed: %s", hipGetErrorName(e)); return 0; }
+        d_src = staged;
+    }
+    e = hipMalloc(&t->data, t->bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(t->data, 0, t->bytes, g.stream);
+    if (e == hipSuccess) e = svr::launch_repack(d_src, (uint16_t*)t->data, nx, ny, nz, layout, t->sy, t->sz, t->bnx, t->bny, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (staged) hipFree(staged);
+    if (e != hipSuccess) { if (t->data) hipFree(t->data); delete t; fail((int)e, "volume texture creation failed: %s", hipGetErrorName(e)); return 0; }
+    uint64_t h = (uint64_t)(uintptr_t)t;
+    g.textures[h] = t;
+    return h;
+}
+
+static uint64_t create_float4_texture(int kind, const float* rgba, int w, int h, int src_is_device)
+{
+    if (ensure_init()) return 0;
+    if (!rgba || w <= 0 || h <= 0) { fail(-6, "texture creation: bad arguments"); return 0; }
+    Texture* t = new Texture();
+    t->magic = TEX_MAGIC; t->kind = kind; t->nx = w; t->ny = h; t->nz = 1; t->layout = 0;
+    t->bytes = (size_t)w * h * 4 * sizeof(float);
+    hipError_t e = hipMalloc(&t->data, t->bytes);
+    if (e == hipSuccess) e = hipMemcpy(t->data, rgba, t->bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e != hipSuccess) { if (t->data) hipFree(t->data); delete t; fail((int)e, "texture upload failed: %s", hipGetErrorName(e)); return 0; }
+    uint64_t hd = (uint64_t)(uintptr_t)t;
+    g.textures[hd] = t;
+    return hd;
+}
+
+uint64_t svr_create_tf_texture(const float* rgba, int n, int src_is_device)
+{
+    if (n > SVR_TF_TABLE_SIZE) { ensure_init(); fail(-6, "transfer-function table of %d entries exceeds the LDS-resident limit of %d", n, SVR_TF_TABLE_SIZE); return 0; }
+    return create_float4_texture(TEX_TF, rgba, n, 1, src_is_device);
+}
+
+int svr_update_tf_texture(uint64_t handle, const float* rgba, int n, int src_is_device)
+{
+    if (ensure_init()) return g.err_code;
+    Texture* t = find_tex(handle, TEX_TF);
+    if (!t) return fail(-2, "svr_update_tf_texture: bad handle");
+    if (n != t->nx || !rgba) return fail(-6, "svr_update_tf_texture: size mismatch (%d vs %d)", n, t->nx);
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpy(t->data, rgba, t->bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return 0;
+}
+
+uint64_t svr_create_env_texture(const float* rgba, int w, int h, int src_is_device)
+{
+    return create_float4_texture(TEX_ENV, rgba, w, h, src_is_device);
+}
+
+int svr_destroy_texture(uint64_t handle)
+{
+    if (ensure_init()) return g.err_code;
+    auto it = g.textures.find(handle);
+    if (it == g.textures.end()) return fail(-2, "svr_destroy_texture: bad handle");
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    Texture* t = it->second;
+    if (t->data) hipFree(t->data);
+    t->magic = 0;
+    delete t;
+    g.textures.erase(it);
+    return 0;
+}
+
+// ---------------- memory helpers ----------------
+void* svr_device_malloc(size_t bytes)
+{
+    if (ensure_init()) return nullptr;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { fail((int)e, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorName(e)); return nullptr; }
+    return p;
+}
+int svr_device_free(void* p) { if (ensure_init()) return g.err_code; HIP_TRY(hipFree(p)); return 0; }
+int svr_memcpy_h2d(void* dst, const void* src, size_t bytes) { if (ensure_init()) return g.err_code; HIP_TRY(hipStreamSynchronize(g.stream)); HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+int svr_memcpy_d2h(void* dst, const void* src, size_t bytes) { if (ensure_init()) return g.err_code; HIP_TRY(hipStreamSynchronize(g.stream)); HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
+int svr_memset_device(void* dst, int value, size_t bytes) { if (ensure_init()) return g.err_code; HIP_TRY(hipMemsetAsync(dst, value, bytes, g.stream)); return 0; }
+
+int svr_render_params_setup_hdr(svr_render_params* p, uint32_t w, uint32_t h)
+{
+    // render_parameters.h:17-23
+    if (ensure_init()) return g.err_code;
+    if (!p) return fail(-4, "svr_render_params_setup_hdr: null");
+    if (svr_render_params_clear(p)) return g.err_code;
+    size_t bytes = sizeof(float) * 3 * (size_t)w * h;
+    HIP_TRY(hipMalloc(&p->hdrBuffer, bytes));
+    HIP_TRY(hipMemset(p->hdrBuffer, 0, bytes));
+    return 0;
+}
+
+int svr_render_params_clear(svr_render_params* p)
+{
+    // render_parameters.h:25-32
+    if (ensure_init()) return g.err_code;
+    if (p && p->hdrBuffer) {
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipFree(p->hdrBuffer));
+        p->hdrBuffer = nullptr;
+    }
+    return 0;
+}
+
+// ---------------- the reference's setup_* (pathtracer.cu:34-68) ----------------
+void setup_volume(const svr_volume* vol)
+{
+    if (ensure_init()) return;
+    if (!vol) { fail(-4, "setup_volume: null"); return; }
+    g.vol = *vol; g.have_vol = true;
+}
+void setup_transferfunction(const svr_transfer_function* tf)
+{
+    if (ensure_init()) return;
+    if (!tf) { fail(-4, "setup_transferfunction: null"); return; }
+    g.tf = *tf; g.have_tf = true;
+}
+void setup_camera(const svr_camera* cam)
+{
+    if (ensure_init()) return;
+    if (!cam) { fail(-4, "setup_camera: null"); return; }
+    g.cam = *cam; g.have_cam = true;
+}
+void setup_env_lights(const svr_environment_light* light)
+{
+    if (ensure_init()) return;
+    if (!light) { fail(-4, "setup_env_lights: null"); return; }
+    g.env = *light;
+}
+void setup_area_lights(svr_area_light* lights, uint32_t n)
+{
+    if (ensure_init()) return;
+    if (n > SVR_MAX_LIGHT_SOURCES) n = SVR_MAX_LIGHT_SOURCES;     // the reference's host guard is off by one (lights.cpp:94)
+    if (n && !lights) { fail(-4, "setup_area_lights: null"); return; }
+    g.num_lights = n;
+    for (uint32_t i = 0; i < n; ++i) g.lights[i] = lights[i];
+}
+
+// ---------------- render entry points ----------------
+void render_pathtracer(void* img, const svr_render_params* renderParams)
+{
+    render_frames(img, renderParams, 1, true);
+}
+
+int svr_render_pathtracer_frames(void* img, const svr_render_params* renderParams, uint32_t nframes)
+{
+    return render_frames(img, renderParams, nframes, true);
+}
+
+int svr_hdr_to_ldr(void* img, const svr_render_params* rp)
+{
+    if (ensure_init()) return g.err_code;
+    if (!rp || !rp->hdrBuffer || !img) return fail(-4, "svr_hdr_to_ldr: null argument");
+    if (!g.have_vol || !g.have_tf || !g.have_cam) return fail(-4, "svr_hdr_to_ldr before setup_*");
+    svr::DevScene s;
+    if (build_scene(g.vol, g.tf, g.cam, s)) return g.err_code;
+    svr::DevWork w;
+    fill_work(w, s.imageW, s.imageH);
+    w.hdr = (float*)rp->hdrBuffer;
+    w.img = (uint8_t*)img;
+    HIP_TRY(svr::launch_tonemap(s, w, g.stream));
+    return 0;
+}
+
+void render_raycasting(void* img, svr_volume* volume, svr_transfer_function* transferFunction, svr_camera* camera, float stepSize)
+{
+    if (ensure_init()) return;
+    if (!img || !volume || !transferFunction || !camera) { fail(-4, "render_raycasting: null argument"); return; }
+    if (!(stepSize > 0.f) || !std::isfinite(stepSize)) { fail(-3, "render_raycasting: stepSize must be finite and > 0 (got %g)", (double)stepSize); return; }
+    svr::DevScene s;
+    if (build_scene(*volume, *transferFunction, *camera, s)) return;
+    svr::DevWork w;
+    fill_work(w, s.imageW, s.imageH);
+    w.img = (uint8_t*)img;
+    hipError_t e = svr::launch_raycast(s, w, stepSize, g.opt_count != 0, g.stream);
+    if (e != hipSuccess) fail((int)e, "render_raycasting launch failed: %s", hipGetErrorName(e));
+}
+
+// ---------------- extensions ----------------
+int svr_set_row_shard(uint32_t strip_rows, uint32_t rank, uint32_t world)
+{
+    if (world <= 1 || strip_rows == 0) { g.strip_rows = 0; g.rank = 0; g.world = 1; return 0; }
+    if (rank >= world) return fail(-6, "svr_set_row_shard: rank %u >= world %u", rank, world);
+    if (strip_rows % 8 != 0) return fail(-6, "svr_set_row_shard: strip_rows must be a multiple of 8 (got %u)", strip_rows);
+    g.strip_rows = strip_rows; g.rank = rank; g.world = world;
+    return 0;
+}
+
+int svr_set_render_window(int x0, int y0, int x1, int y1)
+{
+    g.wx0 = x0; g.wy0 = y0; g.wx1 = x1; g.wy1 = y1;
+    return 0;
+}
+
+int svr_set_option(int key, int value)
+{
+    switch (key) {
+    case SVR_OPT_ENV_ON_ESCAPE: g.opt_env_on_escape = value ? 1 : 0; return 0;
+    case SVR_OPT_KERNEL:
+        if (value < 0 || value > 2) return fail(-6, "SVR_OPT_KERNEL: bad value %d", value);
+        g.opt_kernel = value; return 0;
+    case SVR_OPT_COUNT: g.opt_count = value ? 1 : 0; return 0;
+    case SVR_OPT_TIMING: g.opt_timing = value ? 1 : 0; return 0;
+    case SVR_OPT_SKIP_TONEMAP: g.opt_skip_tonemap = value ? 1 : 0; return 0;
+    case SVR_OPT_BLOCKS_PER_CU:
+        if (value < 0 || value > 8) return fail(-6, "SVR_OPT_BLOCKS_PER_CU: bad value %d", value);
+        g.opt_blocks_per_cu = value; return 0;
+    default: return fail(-6, "svr_set_option: unknown key %d", key);
+    }
+}
+
+int svr_get_option(int key)
+{
+    switch (key) {
+    case SVR_OPT_ENV_ON_ESCAPE: return g.opt_env_on_escape;
+    case SVR_OPT_KERNEL: return g.opt_kernel;
+    case SVR_OPT_COUNT: return g.opt_count;
+    case SVR_OPT_TIMING: return g.opt_timing;
+    case SVR_OPT_SKIP_TONEMAP: return g.opt_skip_tonemap;
+    case SVR_OPT_BLOCKS_PER_CU: return g.opt_blocks_per_cu;
+    default: return -1;
+    }
+}
+
+int svr_get_counters(svr_counters* out)
+{
+    if (ensure_init()) return g.err_code;
+    if (!out) return fail(-4, "svr_get_counters: null");
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpy(out, g.d_counters, sizeof(svr_counters), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int svr_reset_counters(void)
+{
+    if (ensure_init()) return g.err_code;
+    HIP_TRY(hipMemsetAsync(g.d_counters, 0, sizeof(svr_counters), g.stream));
+    return 0;
+}
+
+int svr_get_kernel_time(double* total_ms, uint64_t* launches)
+{
+    if (ensure_init()) return g.err_code;
+    collect_timing();
+    if (total_ms) *total_ms = g.kernel_ms;
+    if (launches) *launches = g.kernel_launches;
+    return 0;
+}
+
+int svr_reset_kernel_time(void)
+{
+    if (ensure_init()) return g.err_code;
+    collect_timing();
+    g.kernel_ms = 0.0;
+    g.kernel_launches = 0;
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,688 @@
+// svr_kernels.hip -- gfx950 kernels of the SunVolumeRender-compatible render path.
+//
+//  k_pathtrace_pixel       one thread per pixel, the shape of the reference's kernel_pathtracer
+//                          (pathtracer.cu:200-280).  Baseline / debugging kernel.
+//  k_pathtrace_persistent  MI355X-first kernel: persistent waves, every lane is a small state
+//                          machine that owns one path at a time; all volume fetches of all
+//                          stages (primary Woodcock walk, gradient taps, shadow Woodcock walk)
+//                          go through ONE shared tap site per scheduler iteration, lanes that
+//                          finish a path are regenerated from a global ticket with
+//                          ballot + mbcnt prefix sums, and the transfer-function LUT lives in
+//                          LDS.  A path's arithmetic does not depend on scheduling, so both
+//                          kernels give bit-identical radiance.
+//  k_tonemap               hdr_to_ldr (pathtracer.cu:282-290)
+//  k_raycast               kernel_raycasting (raycasting.cu:15-67)
+//  k_repack_*              [z][y][x] u16 -> padded LINEAR / BRICK software-texture layouts
+#include "svr_kernels.hpp"
+#include "svr_device.hpp"
+
+namespace svr {
+
+#define SVR_TF_MAX 1024
+#define SVR_TF_PAD 3
+
+// ------------------------------------------------------------------------------------------
+// LDS-resident transfer function.  Entry e of the padded tables holds texel clamp(e-1), so the
+// clamp addressing of tex1D becomes plain adjacent reads (ds_read2_b32 for the alpha pair).
+// ------------------------------------------------------------------------------------------
+struct LdsTF {
+    float4 rgba[SVR_TF_MAX + SVR_TF_PAD];
+    float alpha[SVR_TF_MAX + SVR_TF_PAD];
+};
+
+SVR_DEV void lds_tf_load(LdsTF& L, const DevScene& s)
+{
+    const int n = s.tf_n;
+    const float4* g = reinterpret_cast<const float4*>(s.tf);
+    for (int e = threadIdx.x; e < n + SVR_TF_PAD; e += blockDim.x) {
+        int t = min(max(e - 1, 0), n - 1);
+        float4 v = g[t];
+        L.rgba[e] = v;
+        L.alpha[e] = v.w;
+    }
+    __syncthreads();
+}
+
+SVR_DEV void lds_tf_coord(const DevScene& s, float x, int& e, float& a)
+{
+    float xb = fma_(x, s.tf_nf, -0.5f);
+    xb = fmin_(fmax_(xb, -1.f), s.tf_nf);
+    float fx = __builtin_floorf(xb);
+    a = xb - fx;
+    e = (int)fx + 1;          // in [0, n+1]
+}
+
+SVR_DEV float lds_tf_alpha(const LdsTF& L, const DevScene& s, float x)
+{
+    int e; float a;
+    lds_tf_coord(s, x, e, a);
+    float t0 = L.alpha[e], t1 = L.alpha[e + 1];
+    return lerpf(t0, t1, a);
+}
+
+SVR_DEV void lds_tf_rgba(const LdsTF& L, const DevScene& s, float x, float out[4])
+{
+    int e; float a;
+    lds_tf_coord(s, x, e, a);
+    float4 t0 = L.rgba[e], t1 = L.rgba[e + 1];
+    out[0] = lerpf(t0.x, t1.x, a);
+    out[1] = lerpf(t0.y, t1.y, a);
+    out[2] = lerpf(t0.z, t1.z, a);
+    out[3] = lerpf(t0.w, t1.w, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// pixel enumeration: owned rows (window or interleaved row strips), 8x8 tiles, 64 items per tile
+// ------------------------------------------------------------------------------------------
+SVR_DEV uint32_t owned_row_to_y(const DevWork& w, uint32_t r)
+{
+    if (w.world <= 1u) return w.y0 + r;
+    uint32_t q = r / w.strip_rows;
+    return (q * w.world + w.rank) * w.strip_rows + (r - q * w.strip_rows);
+}
+
+// item -> pixel; false for the padding items of partial tiles
+SVR_DEV bool item_to_pixel(const DevWork& w, uint32_t item, uint32_t& x, uint32_t& y)
+{
+    uint32_t wv = w.x1 - w.x0;
+    uint32_t tiles_x = (wv + 7u) >> 3;
+    uint32_t tile = item >> 6, in = item & 63u;
+    uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    uint32_t px = (tx << 3) + (in & 7u);
+    uint32_t r = (ty << 3) + (in >> 3);
+    if (px >= wv || r >= w.n_rows) return false;
+    x = w.x0 + px;
+    y = owned_row_to_y(w, r);
+    return true;
+}
+
+SVR_DEV unsigned long long wave_sum(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+struct Cnt { uint32_t taps, iters, scatter, shadow, paths, loops; };
+
+SVR_DEV void cnt_flush(const DevWork& w, const Cnt& c)
+{
+    unsigned long long a = wave_sum(c.taps), b = wave_sum(c.iters), d = wave_sum(c.scatter),
+                       e = wave_sum(c.shadow), f = wave_sum(c.paths);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&w.counters[CNT_VOL_TAPS], a);
+        atomicAdd(&w.counters[CNT_WOODCOCK], b);
+        atomicAdd(&w.counters[CNT_SCATTER], d);
+        atomicAdd(&w.counters[CNT_SHADOW], e);
+        atomicAdd(&w.counters[CNT_PATHS], f);
+        atomicAdd(&w.counters[CNT_LOOP], (unsigned long long)c.loops);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Baseline: straight transcription of one path (pathtracer.cu:205-277)
+// ------------------------------------------------------------------------------------------
+template <int LAYOUT, bool COUNT>
+SVR_DEV float sample_distance(const DevScene& s, const LdsTF& tf, v3 orig, v3 dir, Rng& rng,
+                              float& tMin, float& tMax, Cnt& c)
+{
+    // woodcock_tracking.h:20-51
+    float tNear, tFar;
+    if (volume_intersect(s, orig, dir, tNear, tFar)) {
+        tMin = tNear < 0.f ? (float)1e-6 : tNear;
+        tMax = tFar;
+        float t = tMin;
+        for (;;) {
+            if (COUNT) c.iters++;
+            t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+            if (t > tMax) return -SVR_FLT_MAX;
+            v3 p = orig + dir * t;
+            if (COUNT) c.taps++;
+            float intensity = volume_intensity<LAYOUT>(s, p);
+            float sigma_t = lds_tf_alpha(tf, s, intensity);
+            if (rng_uniform(rng) < sigma_t * s.invSigmaMax) break;
+        }
+        return t;
+    }
+    return -SVR_FLT_MAX;
+}
+
+template <int LAYOUT, bool COUNT>
+SVR_DEV v3 trace_path(const DevScene& s, const LdsTF& tf, uint32_t x, uint32_t y,
+                      uint32_t traceDepth, uint32_t hashed, Cnt& c)
+{
+    uint32_t offset = y * s.imageW + x;
+    Rng rng;
+    rng_init(rng, hashed + offset);
+    if (COUNT) c.paths++;
+    v3 L = V3(0.f, 0.f, 0.f), T = V3(1.f, 1.f, 1.f);
+    v3 orig, dir;
+    camera_ray(s, x, y, rng, orig, dir);
+    float ls_t;
+    int ls_id = nearest_light(s, orig, dir, ls_t);
+    for (uint32_t k = 0; k < traceDepth; ++k) {
+        float tMin = (float)1e-6, tMax = SVR_FLT_MAX;
+        float t = sample_distance<LAYOUT, COUNT>(s, tf, orig, dir, rng, tMin, tMax, c);
+        if (k == 0 && ls_id >= 0) {
+            t = t < 0.f ? SVR_FLT_MAX : t;
+            if (ls_t < t) {
+                const DevLight& l = s.lights[ls_id];
+                float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -dir);
+                L = L + (T * V3(l.radiance[0], l.radiance[1], l.radiance[2])) * (cosTerm <= 0.f ? 0.f : 1.f);
+                break;
+            }
+        }
+        if (t < 0.f) {
+            if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+            break;
+        }
+        Shade vs;
+        if (COUNT) { c.scatter++; c.taps += 7; }
+        vs.wo = -dir;
+        vs.pt = orig + dir * t;
+        float intensity = volume_intensity<LAYOUT>(s, vs.pt);
+        lds_tf_rgba(tf, s, intensity, vs.color);
+        vs.gradient = volume_gradient<LAYOUT>(s, vs.pt);
+        float gradMag = __builtin_sqrtf(dot(vs.gradient, vs.gradient));
+        vs.Pbrdf = vs.color[3] * (1.f - expf_(s.pbrdf_c * gradMag * 65535.f * s.invMaxMagnitude));
+        vs.st = (rng_uniform(rng) < vs.Pbrdf) ? 1 : 0;
+        // estimate_direct_light, pathtracer.cu:171-198
+        v3 Ld = V3(0.f, 0.f, 0.f);
+        if (s.num_lights != 0) {
+            int lightId = (int)((float)s.num_lights * rng_uniform(rng));
+            lightId = lightId < (int)s.num_lights ? lightId : (int)s.num_lights - 1;
+            v3 wiL, Li; float pdfL;
+            if (sample_light(s.lights[lightId], vs.pt, rng, wiL, pdfL, Li)) {
+                // transmittance.h:10-17
+                float sMin = (float)1e-6, sMax = SVR_FLT_MAX;
+                if (COUNT) c.shadow++;
+                float ts = sample_distance<LAYOUT, COUNT>(s, tf, vs.pt, wiL, rng, sMin, sMax, c);
+                float Tr = ((ts > sMin) && (ts < sMax)) ? 0.f : 1.f;
+                float kf = Tr * (float)s.num_lights;
+                Ld = ((bsdf_eval(vs, wiL) * kf) * Li) / pdfL;
+            }
+        }
+        L = L + T * Ld;
+        v3 wi; float pdf = 0.f;
+        v3 f = bsdf_sample(vs, wi, pdf, rng);
+        float cosTerm = __builtin_fabsf(dot(normalize(vs.gradient), wi));
+        if (fmax_(f.x, fmax_(f.y, f.z)) > 0.f && pdf > 0.f) {
+            if (vs.st == 0) T = T * (f / (pdf * (1.f - vs.Pbrdf)));
+            else T = T * ((f * cosTerm) / (pdf * vs.Pbrdf));
+        }
+        orig = vs.pt;
+        dir = wi;
+        if (k >= 3) {
+            if (russian_roulette(T, rng)) break;
+        }
+    }
+    return L;
+}
+
+template <int LAYOUT, bool COUNT>
+__global__ __launch_bounds__(256) void k_pathtrace_pixel(const DevScene s, const DevWork w)
+{
+    __shared__ LdsTF tf;
+    lds_tf_load(tf, s);
+    Cnt c = {0, 0, 0, 0, 0, 0};
+    // one 16x16 pixel tile per block, one 8x8 sub-tile per wave
+    uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    uint32_t wv = w.x1 - w.x0;
+    uint32_t tiles16_x = (wv + 15u) >> 4;
+    uint32_t bt = blockIdx.x;
+    uint32_t bty = bt / tiles16_x, btx = bt - bty * tiles16_x;
+    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t px = (btx << 4) + ((wave & 1u) << 3) + (lane & 7u);
+    uint32_t r = (bty << 4) + ((wave >> 1) << 3) + (lane >> 3);
+    (void)item;
+    if (px < wv && r < w.n_rows) {
+        uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
+        size_t off = (size_t)y * s.imageW + x;
+        float* h = w.hdr + 3 * off;
+        v3 acc = (w.frame0 == 0u) ? V3(0.f, 0.f, 0.f) : V3(h[0], h[1], h[2]);   // clear_hdr_buffer iff frameNo==0
+        for (uint32_t f = 0; f < w.nframes; ++f) {
+            uint32_t frameNo = w.frame0 + f;
+            v3 L = trace_path<LAYOUT, COUNT>(s, tf, x, y, w.traceDepth, wang_hash(frameNo), c);
+            float n1 = (float)frameNo + 1.f;                                      // running_estimate, pathtracer.cu:81-84
+            acc = acc + (L - acc) / n1;
+        }
+        h[0] = acc.x; h[1] = acc.y; h[2] = acc.z;
+    }
+    if (COUNT) cnt_flush(w, c);
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent regenerating kernel
+// ------------------------------------------------------------------------------------------
+enum : uint32_t { S_IDLE = 0, S_START, S_WALK, S_GRAD, S_SHADE, S_SCATTER, S_FINISH, S_DONE };
+
+template <int LAYOUT, bool COUNT>
+__global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, const DevWork w)
+{
+    __shared__ LdsTF tf;
+    lds_tf_load(tf, s);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = w.x1 - w.x0;
+    const uint32_t n_tiles = ((wv + 7u) >> 3) * ((w.n_rows + 7u) >> 3);
+    const uint32_t total_items = n_tiles << 6;
+
+    Cnt c = {0, 0, 0, 0, 0, 0};
+
+    // wave-uniform work range
+    uint32_t it_next = 0, it_end = 0;
+    bool exhausted = false;
+
+    // per-lane path state
+    uint32_t state = S_IDLE;
+    Rng rng = {0, 0, 0, 0, 0, 0};
+    v3 o = V3(0, 0, 0), d = V3(0, 0, 1);
+    float t = 0.f, tMin = 0.f, tMax = 0.f;
+    bool shadow = false;
+    uint32_t px = 0, py = 0, frame = 0, k = 0;
+    v3 T = V3(1, 1, 1), L = V3(0, 0, 0), acc = V3(0, 0, 0);
+    float ls_t = 0.f; int ls_id = -1;
+    Shade vs;
+    vs.pt = V3(0, 0, 0); vs.wo = V3(0, 0, 1); vs.gradient = V3(0, 0, 0);
+    vs.color[0] = vs.color[1] = vs.color[2] = vs.color[3] = 0.f; vs.Pbrdf = 0.f; vs.st = 0;
+    uint32_t gi = 0; float gprev = 0.f;
+    // pending next-event estimate
+    bool nee_valid = false; v3 nee_bsdf = V3(0, 0, 0); float nee_pdf = 1.f; int nee_light = 0; float Tr = 1.f;
+
+    for (;;) {
+        if (COUNT) c.loops += (lane == 0);
+
+        // ---- path finished: running_estimate (pathtracer.cu:279) ----
+        if (state == S_FINISH) {
+            uint32_t frameNo = w.frame0 + frame;
+            float n1 = (float)frameNo + 1.f;
+            acc = acc + (L - acc) / n1;
+            frame++;
+            if (frame < w.nframes) state = S_START;
+            else {
+                float* h = w.hdr + 3 * ((size_t)py * s.imageW + px);
+                h[0] = acc.x; h[1] = acc.y; h[2] = acc.z;
+                state = S_IDLE;
+            }
+        }
+
+        // ---- lane regeneration: hand tickets to idle lanes (ballot + mbcnt prefix sum) ----
+        {
+            unsigned long long m_idle = __ballot(state == S_IDLE);
+            if (m_idle != 0ull) {
+                if (!exhausted && it_next == it_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(w.ticket, 64u);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= total_items) exhausted = true;
+                    else { it_next = base; it_end = base + 64u; }
+                }
+                if (exhausted) {
+                    if (state == S_IDLE) state = S_DONE;
+                } else {
+                    uint32_t avail = it_end - it_next;
+                    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+                    uint32_t n_idle = (uint32_t)__popcll(m_idle);
+                    if (state == S_IDLE && rank < avail) {
+                        uint32_t x, y;
+                        if (item_to_pixel(w, it_next + rank, x, y)) {
+                            px = x; py = y; frame = 0;
+                            const float* h = w.hdr + 3 * ((size_t)y * s.imageW + x);
+                            acc = (w.frame0 == 0u) ? V3(0.f, 0.f, 0.f) : V3(h[0], h[1], h[2]);
+                            state = S_START;
+                        }
+                    }
+                    it_next += min(n_idle, avail);
+                }
+            }
+        }
+
+        // ---- start a path: pathtracer.cu:205-215 ----
+        bool pend_miss = false;       // primary walk ended without a collision this iteration
+        if (state == S_START) {
+            uint32_t offset = py * s.imageW + px;
+            rng_init(rng, wang_hash(w.frame0 + frame) + offset);
+            if (COUNT) c.paths++;
+            L = V3(0.f, 0.f, 0.f);
+            T = V3(1.f, 1.f, 1.f);
+            camera_ray(s, px, py, rng, o, d);
+            ls_id = nearest_light(s, o, d, ls_t);
+            k = 0;
+            shadow = false;
+            float tNear, tFar;
+            if (volume_intersect(s, o, d, tNear, tFar)) {
+                tMin = tNear < 0.f ? (float)1e-6 : tNear;
+                tMax = tFar;
+                t = tMin;
+                state = S_WALK;
+            } else {
+                pend_miss = true;
+                state = S_WALK;       // resolved below, no tap issued
+            }
+        }
+
+        // ---- after the shadow walk: finish estimate_direct_light, then sample the BSDF ----
+        if (state == S_SCATTER) {
+            v3 Ld = V3(0.f, 0.f, 0.f);
+            if (nee_valid) {
+                const DevLight& l = s.lights[nee_light];
+                float kf = Tr * (float)s.num_lights;
+                Ld = ((nee_bsdf * kf) * V3(l.radiance[0], l.radiance[1], l.radiance[2])) / nee_pdf;
+            }
+            L = L + T * Ld;
+            if (k + 1u < w.traceDepth) {
+                v3 wi; float pdf = 0.f;
+                v3 f = bsdf_sample(vs, wi, pdf, rng);
+                float cosTerm = __builtin_fabsf(dot(normalize(vs.gradient), wi));
+                if (fmax_(f.x, fmax_(f.y, f.z)) > 0.f && pdf > 0.f) {
+                    if (vs.st == 0) T = T * (f / (pdf * (1.f - vs.Pbrdf)));
+                    else T = T * ((f * cosTerm) / (pdf * vs.Pbrdf));
+                }
+                o = vs.pt;
+                d = wi;
+                bool term = false;
+                if (k >= 3u) term = russian_roulette(T, rng);
+                k++;
+                if (term) state = S_FINISH;
+                else {
+                    shadow = false;
+                    float tNear, tFar;
+                    if (volume_intersect(s, o, d, tNear, tFar)) {
+                        tMin = tNear < 0.f ? (float)1e-6 : tNear;
+                        tMax = tFar;
+                        t = tMin;
+                    } else pend_miss = true;
+                    state = S_WALK;
+                }
+            } else {
+                // last bounce: sample_bsdf / roulette (pathtracer.cu:259-276) cannot reach L any more
+                state = S_FINISH;
+            }
+        }
+
+        // ---- gradient complete: shading decision + next-event estimation set-up ----
+        if (state == S_SHADE) {
+            float gradMag = __builtin_sqrtf(dot(vs.gradient, vs.gradient));
+            vs.Pbrdf = vs.color[3] * (1.f - expf_(s.pbrdf_c * gradMag * 65535.f * s.invMaxMagnitude));
+            vs.st = (rng_uniform(rng) < vs.Pbrdf) ? 1 : 0;
+            nee_valid = false;
+            Tr = 1.f;
+            state = S_SCATTER;
+            if (s.num_lights != 0) {
+                int lightId = (int)((float)s.num_lights * rng_uniform(rng));
+                lightId = lightId < (int)s.num_lights ? lightId : (int)s.num_lights - 1;
+                v3 wiL, Li; float pdfL;
+                if (sample_light(s.lights[lightId], vs.pt, rng, wiL, pdfL, Li)) {
+                    nee_valid = true;
+                    nee_light = lightId;
+                    nee_pdf = pdfL;
+                    nee_bsdf = bsdf_eval(vs, wiL);
+                    if (COUNT) c.shadow++;
+                    // transmittance.h:10-17: ray(start, normalize(end-start)), tMin=1e-6, tMax=FLT_MAX
+                    o = vs.pt;
+                    d = wiL;
+                    tMin = (float)1e-6;
+                    tMax = SVR_FLT_MAX;
+                    float tNear, tFar;
+                    if (volume_intersect(s, o, d, tNear, tFar)) {
+                        tMin = tNear < 0.f ? (float)1e-6 : tNear;
+                        tMax = tFar;
+                        t = tMin;
+                        shadow = true;
+                        state = S_WALK;
+                    }
+                    // else: sample_distance returns -FLT_MAX -> Tr = 1 -> S_SCATTER next iteration
+                }
+            }
+        }
+
+        // ---- the tap site: one volume fetch per lane per iteration, whatever the stage ----
+        bool tapping = false;
+        v3 p = V3(0.f, 0.f, 0.f);
+        if (state == S_WALK && !pend_miss) {
+            // woodcock_tracking.h:34-38
+            if (COUNT) c.iters++;
+            t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+            if (t > tMax) {
+                if (shadow) { Tr = 1.f; state = S_SCATTER; }     // t = -FLT_MAX fails (t > tMin)
+                else pend_miss = true;
+            } else {
+                p = o + d * t;
+                tapping = true;
+            }
+        } else if (state == S_GRAD) {
+            // cuda_volume.h:56-58, taps in the reference's order: +x -x +y -y +z -z
+            float sx = (gi < 2u) ? s.spacing[0] : 0.f;
+            float sy = (gi >= 2u && gi < 4u) ? s.spacing[1] : 0.f;
+            float sz = (gi >= 4u) ? s.spacing[2] : 0.f;
+            if (gi & 1u) p = V3(vs.pt.x - sx, vs.pt.y - sy, vs.pt.z - sz);
+            else p = V3(vs.pt.x + sx, vs.pt.y + sy, vs.pt.z + sz);
+            tapping = true;
+        }
+
+        bool pend_hit = false;
+        float val = 0.f;
+        if (__ballot(tapping) != 0ull) {
+            if (tapping) {
+                if (COUNT) c.taps++;
+                val = volume_intensity<LAYOUT>(s, p);
+                if (state == S_WALK) {
+                    // woodcock_tracking.h:40-44
+                    float sigma_t = lds_tf_alpha(tf, s, val);
+                    if (rng_uniform(rng) < sigma_t * s.invSigmaMax) {
+                        if (shadow) {
+                            Tr = ((t > tMin) && (t < tMax)) ? 0.f : 1.f;
+                            state = S_SCATTER;
+                        } else pend_hit = true;
+                    }
+                } else {
+                    if (gi & 1u) {
+                        float df = gprev - val;
+                        float g = (df * 0.5f) * ((gi == 1u) ? s.invSpacing[0] : (gi == 3u) ? s.invSpacing[1] : s.invSpacing[2]);
+                        if (gi == 1u) vs.gradient.x = g;
+                        else if (gi == 3u) vs.gradient.y = g;
+                        else vs.gradient.z = g;
+                    } else gprev = val;
+                    gi++;
+                    if (gi == 6u) state = S_SHADE;
+                }
+            }
+        }
+
+        // ---- primary walk ended: pathtracer.cu:220-244 ----
+        if (pend_miss || pend_hit) {
+            float tt = pend_hit ? t : -SVR_FLT_MAX;
+            bool done = false;
+            if (k == 0u && ls_id >= 0) {
+                tt = tt < 0.f ? SVR_FLT_MAX : tt;
+                if (ls_t < tt) {
+                    const DevLight& l = s.lights[ls_id];
+                    float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -d);
+                    L = L + (T * V3(l.radiance[0], l.radiance[1], l.radiance[2])) * (cosTerm <= 0.f ? 0.f : 1.f);
+                    done = true;
+                }
+            }
+            if (!done && tt < 0.f) {
+                if (s.env_on_escape) L = L + T * env_radiance(s, d);
+                done = true;
+            }
+            if (done) state = S_FINISH;
+            else {
+                // VolumeSample: the collision point is the last Woodcock tap, so its intensity is `val`
+                if (COUNT) c.scatter++;
+                vs.wo = -d;
+                vs.pt = p;
+                lds_tf_rgba(tf, s, val, vs.color);
+                gi = 0;
+                state = S_GRAD;
+            }
+        }
+
+        if (__ballot(state != S_DONE) == 0ull) break;
+    }
+    if (COUNT) cnt_flush(w, c);
+}
+
+// ------------------------------------------------------------------------------------------
+// hdr_to_ldr, pathtracer.cu:282-290 -- one thread per owned pixel, row-contiguous (coalesced)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tonemap(const DevScene s, const DevWork w)
+{
+    uint32_t wv = w.x1 - w.x0;
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= w.n_items) return;
+    uint32_t r = i / wv, px = i - r * wv;
+    uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
+    size_t off = (size_t)y * s.imageW + x;
+    const float* h = w.hdr + 3 * off;
+    uint32_t rgba = tonemap_pixel(V3(h[0], h[1], h[2]), s.exposure);
+    reinterpret_cast<uint32_t*>(w.img)[off] = rgba;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel_raycasting, raycasting.cu:15-67
+// ------------------------------------------------------------------------------------------
+template <int LAYOUT, bool COUNT>
+__global__ __launch_bounds__(256) void k_raycast(const DevScene s, const DevWork w, float stepSize)
+{
+    __shared__ LdsTF tf;
+    lds_tf_load(tf, s);
+    uint32_t wv = w.x1 - w.x0;
+    uint32_t tiles16_x = (wv + 15u) >> 4;
+    uint32_t bty = blockIdx.x / tiles16_x, btx = blockIdx.x - bty * tiles16_x;
+    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t px = (btx << 4) + ((wave & 1u) << 3) + (lane & 7u);
+    uint32_t r = (bty << 4) + ((wave >> 1) << 3) + (lane >> 3);
+    uint32_t steps = 0;
+    if (px < wv && r < w.n_rows) {
+        uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
+        v3 orig, dir;
+        camera_ray_pinhole(s, x, y, orig, dir);
+        float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
+        float tNear, tFar;
+        if (volume_intersect(s, orig, dir, tNear, tFar)) {
+            float t = tNear;
+            while (t <= tFar) {
+                steps++;
+                v3 p = orig + dir * t;
+                float intensity = volume_intensity<LAYOUT>(s, p);
+                float co[4];
+                lds_tf_rgba(tf, s, intensity, co);
+                v3 gradient = volume_gradient<LAYOUT>(s, p);
+                float gm = __builtin_sqrtf(dot(gradient, gradient));
+                float cosTerm = 1.f, specularTerm = 0.f;
+                if ((double)gm > 1e-3) {
+                    v3 normal = normalize(gradient);
+                    v3 lightDir = normalize(V3(s.cam_pos[0], s.cam_pos[1], s.cam_pos[2]) - p);
+                    cosTerm = __builtin_fabsf(dot(normal, lightDir));
+                    specularTerm = powf_(cosTerm, 30.f);
+                }
+                co[0] = co[0] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
+                co[1] = co[1] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
+                co[2] = co[2] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
+                float wgt = 1.f - La;
+                Lr += wgt * co[0]; Lg += wgt * co[1]; Lb += wgt * co[2]; La += wgt * co[3];
+                if (La > 0.95f) break;
+                t += stepSize * 0.5f;
+            }
+        }
+        Lr = fmin_(Lr, 1.f); Lg = fmin_(Lg, 1.f); Lb = fmin_(Lb, 1.f);
+        uint32_t rgba = to_u8(Lr * 255) | (to_u8(Lg * 255) << 8) | (to_u8(Lb * 255) << 16) | (to_u8(255 * La) << 24);
+        reinterpret_cast<uint32_t*>(w.img)[(size_t)y * s.imageW + x] = rgba;
+    }
+    if (COUNT) {
+        unsigned long long st = wave_sum(steps), tp = wave_sum((unsigned long long)steps * 7ull);
+        if (lane == 0) {
+            atomicAdd(&w.counters[CNT_RAYCAST], st);
+            atomicAdd(&w.counters[CNT_VOL_TAPS], tp);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// volume repack: dst must be zero-filled (apron) before the launch
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_repack(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                int nx, int ny, int nz, int layout, int sy, int sz, int bnx, int bny)
+{
+    size_t n = (size_t)nx * ny * nz;
+    for (size_t e = (size_t)blockIdx.x * 256u + threadIdx.x; e < n; e += (size_t)gridDim.x * 256u) {
+        int x = (int)(e % (size_t)nx);
+        size_t rest = e / (size_t)nx;
+        int y = (int)(rest % (size_t)ny);
+        int z = (int)(rest / (size_t)ny);
+        int i = x + VOL_PAD, j = y + VOL_PAD, k = z + VOL_PAD;
+        size_t o;
+        if (layout == LAYOUT_LINEAR) o = ((size_t)k * sz + (size_t)j * sy) + (size_t)i;
+        else {
+            size_t X = ((size_t)(i >> 3) << 7) + (size_t)(i & 7);
+            size_t Y = (size_t)(j >> 2) * ((size_t)bnx << 7) + (size_t)((j & 3) << 3);
+            size_t Z = (size_t)(k >> 2) * (((size_t)bny * bnx) << 7) + (size_t)((k & 3) << 5);
+            o = X + Y + Z;
+        }
+        dst[o] = src[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+template <int LAYOUT, bool COUNT>
+static hipError_t launch_pathtrace_t(const DevScene& s, const DevWork& w, const LaunchCfg& cfg, hipStream_t st)
+{
+    uint32_t wv = w.x1 - w.x0;
+    if (wv == 0 || w.n_rows == 0) return hipSuccess;
+    if (cfg.kernel == KERNEL_PIXEL) {
+        uint32_t blocks = ((wv + 15u) >> 4) * ((w.n_rows + 15u) >> 4);
+        hipLaunchKernelGGL((k_pathtrace_pixel<LAYOUT, COUNT>), dim3(blocks), dim3(256), 0, st, s, w);
+    } else {
+        uint32_t n_tiles = ((wv + 7u) >> 3) * ((w.n_rows + 7u) >> 3);
+        uint32_t max_blocks = (uint32_t)(cfg.num_cus * cfg.blocks_per_cu);
+        uint32_t need = (n_tiles + 3u) / 4u;                    // 4 waves per block, >= 1 tile per wave
+        uint32_t blocks = need < max_blocks ? need : max_blocks;
+        if (blocks == 0) blocks = 1;
+        hipError_t e = hipMemsetAsync(w.ticket, 0, sizeof(uint32_t), st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_pathtrace_persistent<LAYOUT, COUNT>), dim3(blocks), dim3(256), 0, st, s, w);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pathtrace(const DevScene& s, const DevWork& w, const LaunchCfg& cfg, hipStream_t st)
+{
+    if (s.layout == LAYOUT_LINEAR)
+        return cfg.count ? launch_pathtrace_t<LAYOUT_LINEAR, true>(s, w, cfg, st) : launch_pathtrace_t<LAYOUT_LINEAR, false>(s, w, cfg, st);
+    return cfg.count ? launch_pathtrace_t<LAYOUT_BRICK, true>(s, w, cfg, st) : launch_pathtrace_t<LAYOUT_BRICK, false>(s, w, cfg, st);
+}
+
+hipError_t launch_tonemap(const DevScene& s, const DevWork& w, hipStream_t st)
+{
+    if (w.n_items == 0) return hipSuccess;
+    uint32_t blocks = (w.n_items + 255u) / 256u;
+    hipLaunchKernelGGL(k_tonemap, dim3(blocks), dim3(256), 0, st, s, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_raycast(const DevScene& s, const DevWork& w, float stepSize, bool count, hipStream_t st)
+{
+    uint32_t wv = w.x1 - w.x0;
+    if (wv == 0 || w.n_rows == 0) return hipSuccess;
+    uint32_t blocks = ((wv + 15u) >> 4) * ((w.n_rows + 15u) >> 4);
+    if (s.layout == LAYOUT_LINEAR) {
+        if (count) hipLaunchKernelGGL((k_raycast<LAYOUT_LINEAR, true>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
+        else hipLaunchKernelGGL((k_raycast<LAYOUT_LINEAR, false>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
+    } else {
+        if (count) hipLaunchKernelGGL((k_raycast<LAYOUT_BRICK, true>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
+        else hipLaunchKernelGGL((k_raycast<LAYOUT_BRICK, false>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_repack(const uint16_t* src, uint16_t* dst, int nx, int ny, int nz, int layout,
+                         int sy, int sz, int bnx, int bny, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_repack, dim3(4096), dim3(256), 0, st, src, dst, nx, ny, nz, layout, sy, sz, bnx, bny);
+    return hipGetLastError();
+}
+
+} // namespace svr

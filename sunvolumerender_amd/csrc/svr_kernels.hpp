@@ -1,0 +1,31 @@
+// svr_kernels.hpp -- launch interface between the C-ABI layer (svr_api.hip) and the
+// gfx950 kernels (svr_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "svr_scene.hpp"
+
+namespace svr {
+
+enum { KERNEL_AUTO = 0, KERNEL_PIXEL = 1, KERNEL_PERSISTENT = 2 };
+
+// counter slots (unsigned long long each) -- order of svr_counters in include/svr_abi.h
+enum { CNT_PATHS = 0, CNT_VOL_TAPS, CNT_WOODCOCK, CNT_SCATTER, CNT_SHADOW, CNT_RAYCAST, CNT_LOOP, CNT_RESERVED, CNT_N };
+
+struct LaunchCfg {
+    int kernel;            // KERNEL_*
+    bool count;
+    int num_cus;
+    int blocks_per_cu;     // persistent kernel
+};
+
+// trace `work.nframes` samples per owned pixel, fold into the running mean, optionally tone-map
+hipError_t launch_pathtrace(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
+// hdr_to_ldr over the owned pixels
+hipError_t launch_tonemap(const DevScene& scene, const DevWork& work, hipStream_t stream);
+// kernel_raycasting over the owned pixels
+hipError_t launch_raycast(const DevScene& scene, const DevWork& work, float stepSize, bool count, hipStream_t stream);
+// repack a [nz][ny][nx] u16 volume (device) into the padded LINEAR or BRICK layout (device)
+hipError_t launch_repack(const uint16_t* src, uint16_t* dst, int nx, int ny, int nz, int layout,
+                         int sy, int sz, int bnx, int bny, hipStream_t stream);
+
+} // namespace svr

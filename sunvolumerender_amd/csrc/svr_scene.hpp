@@ -1,0 +1,81 @@
+// svr_scene.hpp -- the device-side scene: what the reference keeps in __constant__
+// globals (pathtracer.cu:34-68), resolved on the host into one POD that is passed BY
+// VALUE as a kernel argument (kernarg segment -> scalar loads; wave-uniform, no
+// hipMemcpyToSymbol, no device sync in setup_*).
+#pragma once
+#include <stdint.h>
+
+namespace svr {
+
+// volume memory layouts (software "texture"; gfx950 exposes no image/sampler path to HIP)
+enum { LAYOUT_LINEAR = 1, LAYOUT_BRICK = 2 };
+constexpr int VOL_PAD = 2;         // zero apron, voxels, each side (border addressing)
+constexpr int BRICK_X = 8, BRICK_Y = 4, BRICK_Z = 4;   // 8*4*4 u16 = 256 B
+
+struct DevLight {                  // cudaAreaLight + values its getters compute
+    float radius;
+    float center[3];
+    float normal[3];
+    float radiance[3];             // cuda_arealight.h:57, evaluated on the host in the same float ops
+    float area;                    // cuda_disk.h:53-56
+};
+
+struct DevScene {
+    // ---- cudaVolume (core/cuda_volume.h) ----
+    float vmin[3];
+    float invSize[3];
+    float clip_vmin[3];            // vmin * (-clip[0])   cuda_bbox.h:38
+    float clip_vmax[3];            // vmax * ( clip[1])   cuda_bbox.h:39
+    float densityScale;
+    float invMaxMagnitude;
+    float gradientFactor;
+    float pbrdf_c;                 // ((-25*gf)*gf)*gf    pathtracer.cu:251 prefix
+    float spacing[3];
+    float invSpacing[3];
+    // software volume texture
+    const uint16_t* vox;
+    int32_t nx, ny, nz;
+    int32_t layout;
+    float fnx, fny, fnz;
+    int32_t sy, sz;                // LINEAR: element strides of the padded array
+    int32_t bnx, bny;              // BRICK: bricks per row / per slab-row
+    // ---- cudaTransferFunction ----
+    const float* tf;               // tf_n x float4
+    int32_t tf_n;
+    float tf_nf;
+    float sigmaMax;
+    float invSigmaMax;             // 1/sigmaMax                      woodcock_tracking.h:30
+    float invSigmaMaxSI;           // 1/(sigmaMax*BASE_SAMPLE_STEP)   woodcock_tracking.h:31
+    // ---- cudaCamera ----
+    uint32_t imageW, imageH;
+    float exposure, apeture, focalLength, aspectRatio, tanFovxOverTwo;
+    float wm1, hm1;                // imageW - 1.f, imageH - 1.f
+    float cam_pos[3], cam_u[3], cam_v[3], cam_w[3];
+    // ---- cudaEnvironmentLight ----
+    const float* env;              // env_h x env_w x float4, or null
+    int32_t env_w, env_h;
+    float env_default[3];
+    float env_intensity;
+    float env_offset[2];
+    uint32_t env_on_escape;
+    // ---- area lights ----
+    uint32_t num_lights;
+    DevLight lights[8];
+};
+
+// per-launch work description
+struct DevWork {
+    float* hdr;                    // W*H packed float3
+    uint8_t* img;                  // W*H RGBA8 or null
+    uint32_t traceDepth;
+    uint32_t frame0;               // first frame number
+    uint32_t nframes;              // frames traced per pixel in this launch
+    uint32_t x0, y0, x1, y1;       // pixel window
+    uint32_t strip_rows, rank, world;   // interleaved row-strip shard (world<=1: off)
+    uint32_t n_rows;               // number of owned rows inside the window
+    uint32_t n_items;              // owned pixels = n_rows * (x1-x0)
+    unsigned long long* counters;  // svr_counters on the device, or null
+    uint32_t* ticket;              // persistent kernel work counter
+};
+
+} // namespace svr

@@ -1,0 +1,62 @@
+"""Shared helpers for the parity tests: run the same Scene through the HIP C-ABI and the oracle."""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import binding
+from sunvolumerender_amd import abi, host, scenes
+
+
+def oracle_frames(scene, nframes, trace_depth=None, window=None, nthreads=0):
+    """Progressive frames 0..nframes-1 through the oracle.  Returns (hdr, img, counters)."""
+    o = binding.OracleScene(scene)
+    hdr = o.new_hdr()
+    img = np.zeros((o.H, o.W, 4), dtype=np.uint8)
+    total = None
+    for f in range(nframes):
+        c = o.render_pathtracer(hdr, f, trace_depth=trace_depth, window=window, img=img, nthreads=nthreads)
+        total = c if total is None else {k: total[k] + c[k] for k in c}
+    return hdr, img, total
+
+
+def hip_frames(dev, scene, nframes, kernel=abi.KERNEL_AUTO, layout=abi.LAYOUT_AUTO, batch=False, count=True,
+               shard=None, window=None):
+    """Progressive frames 0..nframes-1 through libsvr_hip.so, replaying the Canvas protocol."""
+    canvas = host.Canvas(dev, scene.width, scene.height)
+    try:
+        scenes.apply_to_canvas(scene, canvas, layout)
+        dev.set_option(abi.OPT_KERNEL, kernel)
+        dev.set_option(abi.OPT_COUNT, 1 if count else 0)
+        if shard is not None:
+            dev.check(dev.lib.svr_set_row_shard(*shard))
+        if window is not None:
+            dev.check(dev.lib.svr_set_render_window(*window))
+        dev.reset_counters()
+        if batch:
+            canvas.paint_frames(nframes)
+        else:
+            for _ in range(nframes):
+                canvas.paint()
+        dev.synchronize()
+        hdr, img, counters = canvas.read_hdr(), canvas.read_img(), dev.counters()
+    finally:
+        dev.lib.svr_set_row_shard(0, 0, 1)
+        dev.lib.svr_set_render_window(0, 0, -1, -1)
+        dev.set_option(abi.OPT_KERNEL, abi.KERNEL_AUTO)
+        dev.set_option(abi.OPT_COUNT, 0)
+        canvas.close()
+    return hdr, img, counters
+
+
+def bits(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_exact(a, b, what=""):
+    ba, bb = bits(a), bits(b)
+    if not np.array_equal(ba, bb):
+        diff = ba != bb
+        n = int(diff.sum())
+        idx = np.argwhere(diff)[:5]
+        raise AssertionError(f"{what}: {n} of {diff.size} floats differ bitwise; first at {idx.tolist()}; "
+                             f"a={a[tuple(idx[0])]!r} b={b[tuple(idx[0])]!r}")
