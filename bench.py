@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s (paths x spp per second) of the path-tracing hot path on MI355X.
+
+Workload (BASELINE.json metric: "Msamples/sec at 1024^2 on 512^3 volume"): config c3 = 512^3 CT-like
+volume, 1024^2 image, 3 area lights + environment map, GUI-default transfer function, trace depth 1
+(the reference's default, gui/canvas.cpp:17).  A *step* is one progressive-render pass over the whole
+frame: `--spp-per-step` samples for every pixel (default 1 = one render_pathtracer call, exactly the
+reference's per-frame protocol).  With N GPUs the frame is sharded into interleaved 32-row strips
+(global per-pixel seeds, so the assembled image is bit-identical to one GPU) and the HDR accumulation
+buffers are summed onto rank 0 with one RCCL reduce per output, inside the timed region.
+
+One JSON line on rank 0; see the task contract for the field meanings.  `roofline` prices the
+path-tracing kernel by algorithmic bytes (16 B per volume tap + 24 B HDR read-modify-write per pixel
+per launch) over its HIP-event duration; `cpu_baseline` times the CPU oracle (a plain-C
+port of the reference's arithmetic, OpenMP over rows) on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--scene", default="c3")
+    ap.add_argument("--trace-depth", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=1)
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 pixel-per-thread, 2 persistent")
+    ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 linear, 2 brick")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--strip-rows", type=int, default=32)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline budget (0 = skip)")
+    ap.add_argument("--no-count", action="store_true", help="skip the tap-counting pass (roofline.achieved = null)")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, trace_depth, budget_s):
+    """Oracle (oracle/, a port of the reference's arithmetic) timed on the host cores over a bounded,
+    image-representative sample: 8-row strips spread evenly over the frame height."""
+    import numpy as np
+
+    from oracle import binding
+
+    o = binding.OracleScene(scene)
+    cores = o.lib.svo_max_threads()
+    W, H = scene.width, scene.height
+    hdr = o.new_hdr()
+
+    def run(stride):
+        px = 0
+        t0 = time.perf_counter()
+        for y0 in range(0, H, stride):
+            o.render_pathtracer(hdr, 0, trace_depth=trace_depth, window=(0, y0, W, min(H, y0 + 8)), count=False)
+            px += W * (min(H, y0 + 8) - y0)
+        return px, time.perf_counter() - t0
+
+    stride = max(8, (H // 8) // 8 * 8)          # ~8 strips first
+    px, dt = run(stride)
+    pt_budget = budget_s * 0.6
+    if dt < pt_budget * 0.4 and stride > 8:
+        scale = min(pt_budget / max(dt, 1e-3), stride / 8.0)
+        stride2 = max(8, int(stride / scale) // 8 * 8)
+        px, dt = run(stride2)
+        stride = stride2
+    pt_rate = px / dt / 1e6
+    # ray caster (the arithmetic of raycasting.cu, the reference's other render mode)
+    rc_budget = budget_s * 0.4
+    rows = 8
+    t0 = time.perf_counter()
+    rc_px = 0
+    y_list = list(range(0, H, max(8, H // 4 // 8 * 8)))
+    for y0 in y_list:
+        o.render_raycasting(window=(0, y0, W, min(H, y0 + rows)), count=False)
+        rc_px += W * (min(H, y0 + rows) - y0)
+        if time.perf_counter() - t0 > rc_budget:
+            break
+    rc_dt = time.perf_counter() - t0
+    return {
+        "value": round(pt_rate, 4),
+        "unit": "Msamples/s",
+        "cores": int(cores),
+        "kind": "port",
+        "sample": f"path tracer, 1 spp on 8-row strips every {stride} rows of the {W}x{H} frame "
+                  f"({px} paths, {dt:.1f} s, OpenMP {cores} threads)",
+        "raycasting_mpix_s": round(rc_px / rc_dt / 1e6, 5),
+        "raycasting_sample": f"{rc_px} pixels in {rc_dt:.1f} s",
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from sunvolumerender_amd import abi, host, scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    t_setup = time.perf_counter()
+    scene = scenes.make_scene(args.scene, trace_depth=args.trace_depth)
+    W, H = scene.width, scene.height
+    dev = host.Device(local_rank, fatal_errors=False)
+    stream = torch.cuda.current_stream()
+    dev.check(dev.lib.svr_set_stream(C.c_void_p(stream.cuda_stream)))
+    hdr = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    img = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+    canvas = host.Canvas(dev, W, H, img_ptr=img.data_ptr(), hdr_ptr=hdr.data_ptr())
+    scenes.apply_to_canvas(scene, canvas, args.layout)
+    dev.set_option(abi.OPT_KERNEL, args.kernel)
+    if args.blocks_per_cu:
+        dev.set_option(abi.OPT_BLOCKS_PER_CU, args.blocks_per_cu)
+    if world > 1:
+        dev.check(dev.lib.svr_set_row_shard(args.strip_rows, rank, world))
+    S = max(1, args.spp_per_step)
+    t_setup = time.perf_counter() - t_setup
+
+    def step():
+        if S == 1:
+            canvas.paint()
+        else:
+            canvas.paint_frames(S)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- tap-counting pass (untimed): exact algorithmic bytes of the frames about to be timed ----
+    counters = None
+    if not args.no_count:
+        dev.set_option(abi.OPT_COUNT, 1)
+        dev.reset_counters()
+        canvas.ReStartRender()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        counters = dev.counters()
+        dev.set_option(abi.OPT_COUNT, 0)
+
+    # ---- warm-up ----
+    canvas.ReStartRender()
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps (frames 0 .. K*S-1 of a fresh progressive render) ----
+    canvas.ReStartRender()
+    dev.set_option(abi.OPT_TIMING, 1)
+    dev.check(dev.lib.svr_reset_kernel_time())
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.reduce(hdr, dst=0, op=dist.ReduceOp.SUM)     # strips are disjoint; other ranks' rows are zero
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev.set_option(abi.OPT_TIMING, 0)
+    k_ms, k_n = dev.kernel_time()
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    # local counters -> whole-job (every rank counts its own strips)
+    cnt = None
+    if counters is not None:
+        keys = ["paths", "vol_taps", "woodcock_iters", "scatter_events", "shadow_walks"]
+        tc = torch.tensor([counters[k] for k in keys], dtype=torch.float64, device="cuda")
+        local = {k: counters[k] for k in keys}
+        if world > 1:
+            dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+        cnt = {k: int(v) for k, v in zip(keys, tc.tolist())}
+        cnt["local"] = local
+
+    if rank == 0:
+        samples = float(W) * H * S * args.steps
+        value = samples / elapsed / 1e6
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        if cnt is not None and k_n > 0:
+            loc = cnt["local"]
+            n_launch = args.steps
+            owned_px = loc["paths"] / (S * args.steps)
+            bytes_per_launch = (16.0 * loc["vol_taps"] + 24.0 * owned_px * args.steps) / n_launch
+            avg_ms = k_ms / k_n
+            ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5),
+                         "kernel": "k_pathtrace_persistent" if args.kernel in (0, 2) else "k_pathtrace_pixel",
+                         "kernel_avg_ms": round(avg_ms, 4), "kernel_launches": k_n,
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                         "vol_taps_per_path": round(loc["vol_taps"] / max(1, loc["paths"]), 3)})
+        out = {
+            "metric": "Msamples/sec (paths x spp) at 1024^2 on 512^3 volume",
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.scene}: {scene.dim[0]}^3 u16 CT-like volume, {W}x{H} image, "
+                                   f"{len(scene.lights)} area lights, env map {'on' if scene.env_on_escape else 'off'}, "
+                                   f"trace depth {args.trace_depth}, {S} spp per step",
+                       "spp_per_step": S, "trace_depth": args.trace_depth,
+                       "kernel": "persistent" if args.kernel in (0, 2) else "pixel",
+                       "layout": {0: "auto(linear)", 1: "linear", 2: "brick"}[args.layout],
+                       "parallelism": f"row-strip tiles x{world}" if world > 1 else "single GPU",
+                       "device": dev.info(), "setup_s": round(t_setup, 1)},
+            "roofline": roof,
+        }
+        if cnt is not None:
+            out["counters"] = {k: v for k, v in cnt.items() if k != "local"}
+        if args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(scene, args.trace_depth, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    canvas.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

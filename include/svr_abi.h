@@ -183,6 +183,11 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
 #define SVR_OPT_TIMING 4          /* 1: bracket the path-tracing kernel with HIP events */
 #define SVR_OPT_SKIP_TONEMAP 5    /* 1: render_pathtracer does not run hdr_to_ldr (batch rendering) */
 #define SVR_OPT_BLOCKS_PER_CU 6   /* persistent kernel: workgroups per CU (0 = default) */
+#define SVR_OPT_PIPELINE 7        /* 1 (default): trace kernels of consecutive frame groups run on internal streams
+                                     and overlap; the accumulator is still updated in frame order on the caller's
+                                     stream.  0: everything on the caller's stream */
+#define SVR_OPT_REFILL_MIN_IDLE 8 /* persistent kernel: regenerate lanes once this many of a wave's 64 lanes are idle
+                                     (64 = a wave finishes its 8x8 tile before taking the next; default) */
 int svr_set_option(int key, int value);
 int svr_get_option(int key);
 

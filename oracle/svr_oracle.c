@@ -1013,7 +1013,7 @@ void svo_render_pathtracer(const svo_scene* s, float* hdr, uint8_t* img,
     {
         svo_counters local;
         memset(&local, 0, sizeof local);
-#pragma omp for schedule(dynamic, 1)
+#pragma omp for collapse(2) schedule(dynamic, 64)
         for (int y = y0; y < y1; ++y) {
             for (int x = x0; x < x1; ++x) {
                 size_t off = (size_t)y * W + (size_t)x;
@@ -1093,7 +1093,7 @@ void svo_render_raycasting(const svo_scene* s, uint8_t* img, float stepSize,
     {
         svo_counters local;
         memset(&local, 0, sizeof local);
-#pragma omp for schedule(dynamic, 1)
+#pragma omp for collapse(2) schedule(dynamic, 16)
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
                 local.paths++;

@@ -15,7 +15,7 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
-LIB_PATH = LIB_DIR / "libsvr_hip.so"
+LIB_PATH = Path(os.environ["SVR_HIP_LIB"]) if os.environ.get("SVR_HIP_LIB") else LIB_DIR / "libsvr_hip.so"
 ORACLE_DIR = REPO_ROOT / "oracle"
 ORACLE_LIB = ORACLE_DIR / "libsvr_oracle.so"
 

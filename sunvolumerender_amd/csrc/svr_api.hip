@@ -69,8 +69,25 @@ struct Context {
     // device scratch
     unsigned long long* d_counters = nullptr;
     uint32_t* d_ticket = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_pending = false;
+    // Frame pipelining: a render call is cut into groups of <= GROUP frames; each group is traced on
+    // one of NSETS internal streams into that set's scratch slots and resolved (running mean + tone map)
+    // on the caller's stream, so the trace kernels of consecutive frames/calls overlap on the GPU while
+    // the accumulator is still updated strictly in frame order.
+    static constexpr int NSETS = 4, GROUP = 8;
+    struct SlotSet {
+        float* lbuf = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t traced = nullptr, resolved = nullptr;
+        bool used = false;
+    } sets[NSETS];
+    size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
+    int next_set = 0;
+    int opt_pipeline = 1, opt_refill = 64;
+    // ring of HIP event pairs around the path-tracing kernel (SVR_OPT_TIMING); drained lazily so the
+    // timed launches never synchronise with the host
+    static constexpr int EV_RING = 512;
+    hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
+    int ev_head = 0, ev_count = 0;
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     // textures
@@ -125,10 +142,17 @@ int ensure_init()
     g.info = buf;
     HIP_TRY(hipMalloc((void**)&g.d_counters, sizeof(svr_counters)));
     HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
-    HIP_TRY(hipMalloc((void**)&g.d_ticket, 256));
-    HIP_TRY(hipMemset(g.d_ticket, 0, 256));
-    HIP_TRY(hipEventCreate(&g.ev0));
-    HIP_TRY(hipEventCreate(&g.ev1));
+    HIP_TRY(hipMalloc((void**)&g.d_ticket, 64 * Context::NSETS));
+    HIP_TRY(hipMemset(g.d_ticket, 0, 64 * Context::NSETS));
+    for (int i = 0; i < Context::NSETS; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&g.sets[i].stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g.sets[i].traced, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g.sets[i].resolved, hipEventDisableTiming));
+    }
+    for (int i = 0; i < Context::EV_RING; ++i) {
+        HIP_TRY(hipEventCreate(&g.ev0[i]));
+        HIP_TRY(hipEventCreate(&g.ev1[i]));
+    }
     g.inited = true;
     return 0;
 }
@@ -252,6 +276,7 @@ int fill_work(svr::DevWork& w, uint32_t W, uint32_t H)
     memset(&w, 0, sizeof w);
     w.counters = g.d_counters;
     w.ticket = g.d_ticket;
+    w.refill_min_idle = (uint32_t)g.opt_refill;
     w.strip_rows = g.strip_rows ? g.strip_rows : 1;
     w.rank = g.rank;
     w.world = g.world;
@@ -282,14 +307,29 @@ int fill_work(svr::DevWork& w, uint32_t W, uint32_t H)
 
 void collect_timing()
 {
-    if (g.ev_pending) {
+    while (g.ev_count > 0) {
+        int i = (g.ev_head - g.ev_count + 2 * Context::EV_RING) % Context::EV_RING;
         float ms = 0.f;
-        if (hipEventSynchronize(g.ev1) == hipSuccess && hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) {
+        if (hipEventSynchronize(g.ev1[i]) == hipSuccess && hipEventElapsedTime(&ms, g.ev0[i], g.ev1[i]) == hipSuccess) {
             g.kernel_ms += (double)ms;
             g.kernel_launches += 1;
         }
-        g.ev_pending = false;
+        g.ev_count--;
     }
+}
+
+int ensure_slots(uint32_t W, uint32_t H)
+{
+    size_t need = (size_t)3 * W * H;
+    if (g.slot_floats == need) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& st : g.sets) {
+        if (st.lbuf) { HIP_TRY(hipFree(st.lbuf)); st.lbuf = nullptr; }
+        st.used = false;
+    }
+    for (auto& st : g.sets) HIP_TRY(hipMalloc((void**)&st.lbuf, need * sizeof(float) * Context::GROUP));
+    g.slot_floats = need;
+    return 0;
 }
 
 int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool tonemap)
@@ -303,28 +343,52 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     svr::DevScene s;
     if (build_scene(g.vol, g.tf, g.cam, s)) return g.err_code;
     if (add_lights_env(s)) return g.err_code;
-    svr::DevWork w;
-    fill_work(w, s.imageW, s.imageH);
-    w.hdr = (float*)rp->hdrBuffer;
-    w.img = (uint8_t*)img;
-    w.traceDepth = rp->traceDepth;
-    w.frame0 = rp->frameNo;
-    w.nframes = nframes;
+    if ((size_t)3 * s.imageW * s.imageH >= ((size_t)1 << 32)) return fail(-3, "image too large");
+    if (ensure_slots(s.imageW, s.imageH)) return g.err_code;
     svr::LaunchCfg cfg;
     cfg.kernel = g.opt_kernel == svr::KERNEL_AUTO ? svr::KERNEL_PERSISTENT : g.opt_kernel;
     cfg.count = g.opt_count != 0;
     cfg.num_cus = g.num_cus;
     cfg.blocks_per_cu = g.opt_blocks_per_cu > 0 ? g.opt_blocks_per_cu : 4;
-    if (g.opt_timing) {
-        collect_timing();
-        HIP_TRY(hipEventRecord(g.ev0, g.stream));
+    for (uint32_t g0 = 0; g0 < nframes; g0 += Context::GROUP) {
+        uint32_t n = nframes - g0 < (uint32_t)Context::GROUP ? nframes - g0 : (uint32_t)Context::GROUP;
+        bool last = g0 + n >= nframes;
+        int si = g.next_set;
+        g.next_set = (g.next_set + 1) % Context::NSETS;
+        Context::SlotSet& set = g.sets[si];
+        hipStream_t ts = g.opt_pipeline ? set.stream : g.stream;
+        svr::DevWork w;
+        fill_work(w, s.imageW, s.imageH);
+        w.hdr = (float*)rp->hdrBuffer;
+        w.img = (tonemap && last && !g.opt_skip_tonemap) ? (uint8_t*)img : nullptr;
+        w.lbuf = set.lbuf;
+        w.slot_stride = (uint32_t)g.slot_floats;
+        w.ticket = g.d_ticket + 16 * si;
+        w.traceDepth = rp->traceDepth;
+        w.frame0 = rp->frameNo + g0;
+        w.nframes = n;
+        // the scratch slots of this set are free again once their previous resolve has run
+        if (g.opt_pipeline && set.used) HIP_TRY(hipStreamWaitEvent(ts, set.resolved, 0));
+        int slot = -1;
+        if (g.opt_timing) {
+            if (g.ev_count == Context::EV_RING) collect_timing();
+            slot = g.ev_head;
+            HIP_TRY(hipEventRecord(g.ev0[slot], ts));
+        }
+        HIP_TRY(svr::launch_pathtrace(s, w, cfg, ts));
+        if (g.opt_timing) {
+            HIP_TRY(hipEventRecord(g.ev1[slot], ts));
+            g.ev_head = (g.ev_head + 1) % Context::EV_RING;
+            g.ev_count++;
+        }
+        if (g.opt_pipeline) {
+            HIP_TRY(hipEventRecord(set.traced, ts));
+            HIP_TRY(hipStreamWaitEvent(g.stream, set.traced, 0));
+        }
+        HIP_TRY(svr::launch_resolve(s, w, g.stream));
+        if (g.opt_pipeline) HIP_TRY(hipEventRecord(set.resolved, g.stream));
+        set.used = true;
     }
-    HIP_TRY(svr::launch_pathtrace(s, w, cfg, g.stream));
-    if (g.opt_timing) {
-        HIP_TRY(hipEventRecord(g.ev1, g.stream));
-        g.ev_pending = true;
-    }
-    if (tonemap && img && !g.opt_skip_tonemap) HIP_TRY(svr::launch_tonemap(s, w, g.stream));
     return 0;
 }
 
@@ -354,10 +418,18 @@ void svr_shutdown(void)
         delete kv.second;
     }
     g.textures.clear();
+    for (auto& st : g.sets) {
+        if (st.lbuf) hipFree(st.lbuf);
+        if (st.stream) hipStreamDestroy(st.stream);
+        if (st.traced) hipEventDestroy(st.traced);
+        if (st.resolved) hipEventDestroy(st.resolved);
+    }
     if (g.d_counters) hipFree(g.d_counters);
     if (g.d_ticket) hipFree(g.d_ticket);
-    if (g.ev0) hipEventDestroy(g.ev0);
-    if (g.ev1) hipEventDestroy(g.ev1);
+    for (int i = 0; i < Context::EV_RING; ++i) {
+        if (g.ev0[i]) hipEventDestroy(g.ev0[i]);
+        if (g.ev1[i]) hipEventDestroy(g.ev1[i]);
+    }
     int fatal = g.fatal;
     g = Context();
     g.fatal = fatal;
@@ -366,7 +438,9 @@ void svr_shutdown(void)
 int svr_set_stream(void* hip_stream)
 {
     if (ensure_init()) return g.err_code;
+    HIP_TRY(hipDeviceSynchronize());
     collect_timing();
+    for (auto& st : g.sets) st.used = false;
     g.stream = (hipStream_t)hip_stream;
     return 0;
 }
@@ -454,7 +528,7 @@ int svr_update_tf_texture(uint64_t handle, const float* rgba, int n, int src_is_
     Texture* t = find_tex(handle, TEX_TF);
     if (!t) return fail(-2, "svr_update_tf_texture: bad handle");
     if (n != t->nx || !rgba) return fail(-6, "svr_update_tf_texture: size mismatch (%d vs %d)", n, t->nx);
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(t->data, rgba, t->bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     return 0;
 }
@@ -469,7 +543,7 @@ int svr_destroy_texture(uint64_t handle)
     if (ensure_init()) return g.err_code;
     auto it = g.textures.find(handle);
     if (it == g.textures.end()) return fail(-2, "svr_destroy_texture: bad handle");
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipDeviceSynchronize());
     Texture* t = it->second;
     if (t->data) hipFree(t->data);
     t->magic = 0;
@@ -619,6 +693,10 @@ int svr_set_option(int key, int value)
     case SVR_OPT_BLOCKS_PER_CU:
         if (value < 0 || value > 8) return fail(-6, "SVR_OPT_BLOCKS_PER_CU: bad value %d", value);
         g.opt_blocks_per_cu = value; return 0;
+    case SVR_OPT_PIPELINE: g.opt_pipeline = value ? 1 : 0; return 0;
+    case SVR_OPT_REFILL_MIN_IDLE:
+        if (value < 1 || value > 64) return fail(-6, "SVR_OPT_REFILL_MIN_IDLE: bad value %d (1..64)", value);
+        g.opt_refill = value; return 0;
     default: return fail(-6, "svr_set_option: unknown key %d", key);
     }
 }
@@ -632,6 +710,8 @@ int svr_get_option(int key)
     case SVR_OPT_TIMING: return g.opt_timing;
     case SVR_OPT_SKIP_TONEMAP: return g.opt_skip_tonemap;
     case SVR_OPT_BLOCKS_PER_CU: return g.opt_blocks_per_cu;
+    case SVR_OPT_PIPELINE: return g.opt_pipeline;
+    case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     default: return -1;
     }
 }
@@ -640,7 +720,7 @@ int svr_get_counters(svr_counters* out)
 {
     if (ensure_init()) return g.err_code;
     if (!out) return fail(-4, "svr_get_counters: null");
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, g.d_counters, sizeof(svr_counters), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -648,7 +728,8 @@ int svr_get_counters(svr_counters* out)
 int svr_reset_counters(void)
 {
     if (ensure_init()) return g.err_code;
-    HIP_TRY(hipMemsetAsync(g.d_counters, 0, sizeof(svr_counters), g.stream));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
     return 0;
 }
 

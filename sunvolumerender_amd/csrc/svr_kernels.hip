@@ -19,6 +19,10 @@
 namespace svr {
 
 #define SVR_TF_MAX 1024
+// Hang guard, not part of the algorithm: a single Woodcock walk is abandoned (treated as leaving the
+// volume) after 2^20 iterations.  Unreachable for sane scenes (expected iterations = sigma_max x chord
+// length, ~10^2..10^3); it only bounds kernels fed degenerate majorants so a launch always drains.
+#define SVR_WALK_GUARD (1u << 20)
 #define SVR_TF_PAD 3
 
 // ------------------------------------------------------------------------------------------
@@ -81,12 +85,16 @@ SVR_DEV uint32_t owned_row_to_y(const DevWork& w, uint32_t r)
     return (q * w.world + w.rank) * w.strip_rows + (r - q * w.strip_rows);
 }
 
-// item -> pixel; false for the padding items of partial tiles
-SVR_DEV bool item_to_pixel(const DevWork& w, uint32_t item, uint32_t& x, uint32_t& y)
+// item -> (pixel, frame slot).  Items enumerate wave-tasks tile-major: task = tile * nframes + slot,
+// 64 items (one 8x8 tile) per task, so concurrently running waves work on neighbouring tubes of the
+// volume.  false for the padding items of partial tiles.
+SVR_DEV bool item_to_pixel(const DevWork& w, uint32_t item, uint32_t& x, uint32_t& y, uint32_t& slot)
 {
     uint32_t wv = w.x1 - w.x0;
     uint32_t tiles_x = (wv + 7u) >> 3;
-    uint32_t tile = item >> 6, in = item & 63u;
+    uint32_t task = item >> 6, in = item & 63u;
+    uint32_t tile = task / w.nframes;
+    slot = task - tile * w.nframes;
     uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
     uint32_t px = (tx << 3) + (in & 7u);
     uint32_t r = (ty << 3) + (in >> 3);
@@ -131,10 +139,10 @@ SVR_DEV float sample_distance(const DevScene& s, const LdsTF& tf, v3 orig, v3 di
         tMin = tNear < 0.f ? (float)1e-6 : tNear;
         tMax = tFar;
         float t = tMin;
-        for (;;) {
+        for (uint32_t guard = 0;; ++guard) {
             if (COUNT) c.iters++;
             t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-            if (t > tMax) return -SVR_FLT_MAX;
+            if (t > tMax || guard >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
             v3 p = orig + dir * t;
             if (COUNT) c.taps++;
             float intensity = volume_intensity<LAYOUT>(s, p);
@@ -218,34 +226,29 @@ SVR_DEV v3 trace_path(const DevScene& s, const LdsTF& tf, uint32_t x, uint32_t y
     return L;
 }
 
+#ifndef SVR_WAVES_PER_EU_PIXEL
+#define SVR_WAVES_PER_EU_PIXEL 4
+#endif
 template <int LAYOUT, bool COUNT>
-__global__ __launch_bounds__(256) void k_pathtrace_pixel(const DevScene s, const DevWork w)
+__global__ __launch_bounds__(256, SVR_WAVES_PER_EU_PIXEL) void k_pathtrace_pixel(const DevScene s, const DevWork w)
 {
     __shared__ LdsTF tf;
     lds_tf_load(tf, s);
     Cnt c = {0, 0, 0, 0, 0, 0};
-    // one 16x16 pixel tile per block, one 8x8 sub-tile per wave
-    uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    // one (16x16 pixel tile, frame slot) per block, one 8x8 sub-tile per wave
     uint32_t wv = w.x1 - w.x0;
     uint32_t tiles16_x = (wv + 15u) >> 4;
-    uint32_t bt = blockIdx.x;
+    uint32_t bt = blockIdx.x / w.nframes;
+    uint32_t slot = blockIdx.x - bt * w.nframes;
     uint32_t bty = bt / tiles16_x, btx = bt - bty * tiles16_x;
     uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t px = (btx << 4) + ((wave & 1u) << 3) + (lane & 7u);
     uint32_t r = (bty << 4) + ((wave >> 1) << 3) + (lane >> 3);
-    (void)item;
     if (px < wv && r < w.n_rows) {
         uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
-        size_t off = (size_t)y * s.imageW + x;
-        float* h = w.hdr + 3 * off;
-        v3 acc = (w.frame0 == 0u) ? V3(0.f, 0.f, 0.f) : V3(h[0], h[1], h[2]);   // clear_hdr_buffer iff frameNo==0
-        for (uint32_t f = 0; f < w.nframes; ++f) {
-            uint32_t frameNo = w.frame0 + f;
-            v3 L = trace_path<LAYOUT, COUNT>(s, tf, x, y, w.traceDepth, wang_hash(frameNo), c);
-            float n1 = (float)frameNo + 1.f;                                      // running_estimate, pathtracer.cu:81-84
-            acc = acc + (L - acc) / n1;
-        }
-        h[0] = acc.x; h[1] = acc.y; h[2] = acc.z;
+        v3 L = trace_path<LAYOUT, COUNT>(s, tf, x, y, w.traceDepth, wang_hash(w.frame0 + slot), c);
+        float* o = w.lbuf + (size_t)slot * w.slot_stride + 3 * ((size_t)y * s.imageW + x);
+        o[0] = L.x; o[1] = L.y; o[2] = L.z;
     }
     if (COUNT) cnt_flush(w, c);
 }
@@ -255,8 +258,11 @@ __global__ __launch_bounds__(256) void k_pathtrace_pixel(const DevScene s, const
 // ------------------------------------------------------------------------------------------
 enum : uint32_t { S_IDLE = 0, S_START, S_WALK, S_GRAD, S_SHADE, S_SCATTER, S_FINISH, S_DONE };
 
+#ifndef SVR_WAVES_PER_EU
+#define SVR_WAVES_PER_EU 4
+#endif
 template <int LAYOUT, bool COUNT>
-__global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, const DevWork w)
+__global__ __launch_bounds__(256, SVR_WAVES_PER_EU) void k_pathtrace_persistent(const DevScene s, const DevWork w)
 {
     __shared__ LdsTF tf;
     lds_tf_load(tf, s);
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = w.x1 - w.x0;
     const uint32_t n_tiles = ((wv + 7u) >> 3) * ((w.n_rows + 7u) >> 3);
-    const uint32_t total_items = n_tiles << 6;
+    const uint32_t total_items = (n_tiles * w.nframes) << 6;
 
     Cnt c = {0, 0, 0, 0, 0, 0};
 
@@ -278,37 +284,33 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, 
     v3 o = V3(0, 0, 0), d = V3(0, 0, 1);
     float t = 0.f, tMin = 0.f, tMax = 0.f;
     bool shadow = false;
-    uint32_t px = 0, py = 0, frame = 0, k = 0;
-    v3 T = V3(1, 1, 1), L = V3(0, 0, 0), acc = V3(0, 0, 0);
+    uint32_t px = 0, py = 0, fslot = 0, k = 0;
+    v3 T = V3(1, 1, 1), L = V3(0, 0, 0);
     float ls_t = 0.f; int ls_id = -1;
     Shade vs;
     vs.pt = V3(0, 0, 0); vs.wo = V3(0, 0, 1); vs.gradient = V3(0, 0, 0);
     vs.color[0] = vs.color[1] = vs.color[2] = vs.color[3] = 0.f; vs.Pbrdf = 0.f; vs.st = 0;
     uint32_t gi = 0; float gprev = 0.f;
+    uint32_t guard = 0;
     // pending next-event estimate
     bool nee_valid = false; v3 nee_bsdf = V3(0, 0, 0); float nee_pdf = 1.f; int nee_light = 0; float Tr = 1.f;
 
     for (;;) {
         if (COUNT) c.loops += (lane == 0);
 
-        // ---- path finished: running_estimate (pathtracer.cu:279) ----
+        // ---- path finished: hand its radiance to the resolve pass (running_estimate, pathtracer.cu:279) ----
         if (state == S_FINISH) {
-            uint32_t frameNo = w.frame0 + frame;
-            float n1 = (float)frameNo + 1.f;
-            acc = acc + (L - acc) / n1;
-            frame++;
-            if (frame < w.nframes) state = S_START;
-            else {
-                float* h = w.hdr + 3 * ((size_t)py * s.imageW + px);
-                h[0] = acc.x; h[1] = acc.y; h[2] = acc.z;
-                state = S_IDLE;
-            }
+            float* o_ = w.lbuf + (size_t)fslot * w.slot_stride + 3 * ((size_t)py * s.imageW + px);
+            o_[0] = L.x; o_[1] = L.y; o_[2] = L.z;
+            state = S_IDLE;
         }
 
         // ---- lane regeneration: hand tickets to idle lanes (ballot + mbcnt prefix sum) ----
         {
             unsigned long long m_idle = __ballot(state == S_IDLE);
-            if (m_idle != 0ull) {
+            unsigned long long m_busy = __ballot(state != S_IDLE && state != S_DONE);
+            uint32_t n_idle = (uint32_t)__popcll(m_idle);
+            if (m_idle != 0ull && (n_idle >= w.refill_min_idle || m_busy == 0ull)) {
                 if (!exhausted && it_next == it_end) {
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(w.ticket, 64u);
@@ -322,13 +324,10 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, 
                     uint32_t avail = it_end - it_next;
                     uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32),
                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
-                    uint32_t n_idle = (uint32_t)__popcll(m_idle);
                     if (state == S_IDLE && rank < avail) {
-                        uint32_t x, y;
-                        if (item_to_pixel(w, it_next + rank, x, y)) {
-                            px = x; py = y; frame = 0;
-                            const float* h = w.hdr + 3 * ((size_t)y * s.imageW + x);
-                            acc = (w.frame0 == 0u) ? V3(0.f, 0.f, 0.f) : V3(h[0], h[1], h[2]);
+                        uint32_t x, y, sl;
+                        if (item_to_pixel(w, it_next + rank, x, y, sl)) {
+                            px = x; py = y; fslot = sl;
                             state = S_START;
                         }
                     }
@@ -341,7 +340,7 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, 
         bool pend_miss = false;       // primary walk ended without a collision this iteration
         if (state == S_START) {
             uint32_t offset = py * s.imageW + px;
-            rng_init(rng, wang_hash(w.frame0 + frame) + offset);
+            rng_init(rng, wang_hash(w.frame0 + fslot) + offset);
             if (COUNT) c.paths++;
             L = V3(0.f, 0.f, 0.f);
             T = V3(1.f, 1.f, 1.f);
@@ -354,6 +353,7 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, 
                 tMin = tNear < 0.f ? (float)1e-6 : tNear;
                 tMax = tFar;
                 t = tMin;
+                guard = 0;
                 state = S_WALK;
             } else {
                 pend_miss = true;
@@ -391,6 +391,7 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, 
                         tMin = tNear < 0.f ? (float)1e-6 : tNear;
                         tMax = tFar;
                         t = tMin;
+                        guard = 0;
                     } else pend_miss = true;
                     state = S_WALK;
                 }
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, 
                         tMin = tNear < 0.f ? (float)1e-6 : tNear;
                         tMax = tFar;
                         t = tMin;
+                        guard = 0;
                         shadow = true;
                         state = S_WALK;
                     }
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, 
             // woodcock_tracking.h:34-38
             if (COUNT) c.iters++;
             t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-            if (t > tMax) {
+            if (t > tMax || ++guard > SVR_WALK_GUARD) {
                 if (shadow) { Tr = 1.f; state = S_SCATTER; }     // t = -FLT_MAX fails (t > tMin)
                 else pend_miss = true;
             } else {
@@ -521,6 +523,32 @@ __global__ __launch_bounds__(256) void k_pathtrace_persistent(const DevScene s, 
         if (__ballot(state != S_DONE) == 0ull) break;
     }
     if (COUNT) cnt_flush(w, c);
+}
+
+// ------------------------------------------------------------------------------------------
+// Resolve: clear_hdr_buffer (iff frameNo == 0, pathtracer.cu:86-94,297-300) + running_estimate
+// (pathtracer.cu:81-84,279) for the frames of the group IN FRAME ORDER + hdr_to_ldr
+// (pathtracer.cu:282-290).  One thread per owned pixel, row-contiguous: coalesced reads of the
+// scratch slots and coalesced framebuffer writes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resolve(const DevScene s, const DevWork w)
+{
+    uint32_t wv = w.x1 - w.x0;
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= w.n_items) return;
+    uint32_t r = i / wv, px = i - r * wv;
+    uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
+    size_t off = (size_t)y * s.imageW + x;
+    float* h = w.hdr + 3 * off;
+    v3 acc = (w.frame0 == 0u) ? V3(0.f, 0.f, 0.f) : V3(h[0], h[1], h[2]);
+    for (uint32_t f = 0; f < w.nframes; ++f) {
+        const float* l = w.lbuf + (size_t)f * w.slot_stride + 3 * off;
+        v3 L = V3(l[0], l[1], l[2]);
+        float n1 = (float)(w.frame0 + f) + 1.f;
+        acc = acc + (L - acc) / n1;
+    }
+    h[0] = acc.x; h[1] = acc.y; h[2] = acc.z;
+    if (w.img) reinterpret_cast<uint32_t*>(w.img)[off] = tonemap_pixel(acc, s.exposure);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -633,10 +661,10 @@ static hipError_t launch_pathtrace_t(const DevScene& s, const DevWork& w, const 
     uint32_t wv = w.x1 - w.x0;
     if (wv == 0 || w.n_rows == 0) return hipSuccess;
     if (cfg.kernel == KERNEL_PIXEL) {
-        uint32_t blocks = ((wv + 15u) >> 4) * ((w.n_rows + 15u) >> 4);
+        uint32_t blocks = ((wv + 15u) >> 4) * ((w.n_rows + 15u) >> 4) * w.nframes;
         hipLaunchKernelGGL((k_pathtrace_pixel<LAYOUT, COUNT>), dim3(blocks), dim3(256), 0, st, s, w);
     } else {
-        uint32_t n_tiles = ((wv + 7u) >> 3) * ((w.n_rows + 7u) >> 3);
+        uint32_t n_tiles = ((wv + 7u) >> 3) * ((w.n_rows + 7u) >> 3) * w.nframes;
         uint32_t max_blocks = (uint32_t)(cfg.num_cus * cfg.blocks_per_cu);
         uint32_t need = (n_tiles + 3u) / 4u;                    // 4 waves per block, >= 1 tile per wave
         uint32_t blocks = need < max_blocks ? need : max_blocks;
@@ -653,6 +681,14 @@ hipError_t launch_pathtrace(const DevScene& s, const DevWork& w, const LaunchCfg
     if (s.layout == LAYOUT_LINEAR)
         return cfg.count ? launch_pathtrace_t<LAYOUT_LINEAR, true>(s, w, cfg, st) : launch_pathtrace_t<LAYOUT_LINEAR, false>(s, w, cfg, st);
     return cfg.count ? launch_pathtrace_t<LAYOUT_BRICK, true>(s, w, cfg, st) : launch_pathtrace_t<LAYOUT_BRICK, false>(s, w, cfg, st);
+}
+
+hipError_t launch_resolve(const DevScene& s, const DevWork& w, hipStream_t st)
+{
+    if (w.n_items == 0) return hipSuccess;
+    uint32_t blocks = (w.n_items + 255u) / 256u;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, st, s, w);
+    return hipGetLastError();
 }
 
 hipError_t launch_tonemap(const DevScene& s, const DevWork& w, hipStream_t st)

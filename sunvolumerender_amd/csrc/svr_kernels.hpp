@@ -18,8 +18,10 @@ struct LaunchCfg {
     int blocks_per_cu;     // persistent kernel
 };
 
-// trace `work.nframes` samples per owned pixel, fold into the running mean, optionally tone-map
+// trace work.nframes paths per owned pixel into the scratch slots work.lbuf
 hipError_t launch_pathtrace(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
+// fold the scratch slots into the running mean (frame order) and, if work.img, tone-map
+hipError_t launch_resolve(const DevScene& scene, const DevWork& work, hipStream_t stream);
 // hdr_to_ldr over the owned pixels
 hipError_t launch_tonemap(const DevScene& scene, const DevWork& work, hipStream_t stream);
 // kernel_raycasting over the owned pixels

@@ -63,17 +63,23 @@ struct DevScene {
     DevLight lights[8];
 };
 
-// per-launch work description
+// per-launch work description.  Tracing and accumulation are decoupled: the trace kernel writes the
+// radiance of each path into a scratch slot lbuf[slot][pixel] (one slot per frame of the group),
+// and the resolve kernel folds the slots into the running mean in frame order (bit-identical to
+// the reference's sequential running_estimate) and tone-maps, with coalesced row-contiguous access.
 struct DevWork {
-    float* hdr;                    // W*H packed float3
-    uint8_t* img;                  // W*H RGBA8 or null
+    float* hdr;                    // W*H packed float3 (resolve only)
+    uint8_t* img;                  // W*H RGBA8 or null (resolve only)
+    float* lbuf;                   // scratch radiance: nframes slots of slot_stride floats
+    uint32_t slot_stride;          // floats per slot = 3*W*H
     uint32_t traceDepth;
-    uint32_t frame0;               // first frame number
-    uint32_t nframes;              // frames traced per pixel in this launch
+    uint32_t frame0;               // first frame number of this group
+    uint32_t nframes;              // frames in this group (= slots used)
     uint32_t x0, y0, x1, y1;       // pixel window
     uint32_t strip_rows, rank, world;   // interleaved row-strip shard (world<=1: off)
     uint32_t n_rows;               // number of owned rows inside the window
     uint32_t n_items;              // owned pixels = n_rows * (x1-x0)
+    uint32_t refill_min_idle;      // persistent kernel: regenerate lanes once this many are idle (64 = tile-synchronous)
     unsigned long long* counters;  // svr_counters on the device, or null
     uint32_t* ticket;              // persistent kernel work counter
 };

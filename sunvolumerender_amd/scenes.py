@@ -239,8 +239,19 @@ _VOLUME_CACHE: dict = {}
 def _volume(kind: str, n: int) -> Tuple[np.ndarray, float]:
     key = (kind, n)
     if key not in _VOLUME_CACHE:
-        vox = make_sphere_volume(n) if kind == "sphere" else make_ct_head_volume(n)
-        _VOLUME_CACHE[key] = (vox, max_gradient_magnitude(vox))
+        import os
+        cache_dir = os.environ.get("SVR_SCENE_CACHE")          # optional on-disk cache of generated volumes
+        path = os.path.join(cache_dir, f"{kind}_{n}.npz") if cache_dir else None
+        if path and os.path.exists(path):
+            z = np.load(path)
+            _VOLUME_CACHE[key] = (z["vox"], float(z["maxmag"]))
+        else:
+            vox = make_sphere_volume(n) if kind == "sphere" else make_ct_head_volume(n)
+            mm = max_gradient_magnitude(vox)
+            _VOLUME_CACHE[key] = (vox, mm)
+            if path:
+                os.makedirs(cache_dir, exist_ok=True)
+                np.savez(path, vox=vox, maxmag=np.float64(mm))
     return _VOLUME_CACHE[key]
 
 

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Timing sweep over kernel options for one library build (select with SVR_HIP_LIB).
+usage: tools/exp.py [--scene c3] [--frames 16] combos...   combo = kernel,layout,bpc,refill,spp,pipeline"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from sunvolumerender_amd import abi, host, scenes  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="c3")
+ap.add_argument("--frames", type=int, default=16)
+ap.add_argument("--depth", type=int, default=1)
+ap.add_argument("combos", nargs="+")
+a = ap.parse_args()
+
+sc = scenes.make_scene(a.scene, trace_depth=a.depth)
+dev = host.Device(0)
+print("lib:", abi.library_path().name, "|", dev.info(), flush=True)
+canv = {}
+for combo in a.combos:
+    k, lay, bpc, refill, spp, pipe = [int(v) for v in combo.split(",")]
+    if lay not in canv:
+        for c in canv.values():
+            c.close()
+        canv.clear()
+        c = host.Canvas(dev, sc.width, sc.height)
+        scenes.apply_to_canvas(sc, c, lay)
+        canv[lay] = c
+    c = canv[lay]
+    dev.set_option(abi.OPT_KERNEL, k)
+    dev.set_option(abi.OPT_BLOCKS_PER_CU, bpc)
+    dev.set_option(abi.OPT_REFILL_MIN_IDLE, refill)
+    dev.set_option(abi.OPT_PIPELINE, pipe)
+    best = None
+    for rep in range(3):
+        c.ReStartRender()
+        dev.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        while n < a.frames:
+            if spp == 1:
+                c.paint()
+            else:
+                c.paint_frames(spp)
+            n += spp
+        dev.synchronize()
+        dt = (time.perf_counter() - t0) / n * 1e3
+        best = dt if best is None else min(best, dt)
+    print(f"kernel={k} layout={lay} bpc={bpc} refill={refill:2d} spp/call={spp:2d} pipeline={pipe}:  {best:7.3f} ms/frame  "
+          f"{sc.width * sc.height / best / 1e3:8.1f} Msamples/s", flush=True)
+for c in canv.values():
+    c.close()
