@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--scene", default="c3")
     ap.add_argument("--trace-depth", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=1)
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 pixel-per-thread, 2 persistent")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto(=2), 1 block-per-tile baseline, 2 persistent tile kernel, 3 lane state machine")
     ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 linear, 2 brick")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--strip-rows", type=int, default=32)
@@ -191,7 +191,7 @@ def main():
     # local counters -> whole-job (every rank counts its own strips)
     cnt = None
     if counters is not None:
-        keys = ["paths", "vol_taps", "woodcock_iters", "scatter_events", "shadow_walks"]
+        keys = ["paths", "vol_taps", "vol_taps_executed", "woodcock_iters", "scatter_events", "shadow_walks"]
         tc = torch.tensor([counters[k] for k in keys], dtype=torch.float64, device="cuda")
         local = {k: counters[k] for k in keys}
         if world > 1:
@@ -211,7 +211,7 @@ def main():
             avg_ms = k_ms / k_n
             ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5),
-                         "kernel": "k_pathtrace_persistent" if args.kernel in (0, 2) else "k_pathtrace_pixel",
+                         "kernel": {0: "k_trace_tile", 1: "k_pathtrace_pixel", 2: "k_trace_tile", 3: "k_pathtrace_uloop"}[args.kernel],
                          "kernel_avg_ms": round(avg_ms, 4), "kernel_launches": k_n,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "vol_taps_per_path": round(loc["vol_taps"] / max(1, loc["paths"]), 3)})
@@ -232,8 +232,8 @@ def main():
                                    f"{len(scene.lights)} area lights, env map {'on' if scene.env_on_escape else 'off'}, "
                                    f"trace depth {args.trace_depth}, {S} spp per step",
                        "spp_per_step": S, "trace_depth": args.trace_depth,
-                       "kernel": "persistent" if args.kernel in (0, 2) else "pixel",
-                       "layout": {0: "auto(linear)", 1: "linear", 2: "brick"}[args.layout],
+                       "kernel": {0: "tile", 1: "pixel", 2: "tile", 3: "uloop"}[args.kernel],
+                       "layout": {0: "auto(brick)", 1: "linear", 2: "brick"}[args.layout],
                        "parallelism": f"row-strip tiles x{world}" if world > 1 else "single GPU",
                        "device": dev.info(), "setup_s": round(t_setup, 1)},
             "roofline": roof,

@@ -178,7 +178,9 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
 
 #define SVR_OPT_ENV_ON_ESCAPE 1   /* 1: add T*env(dir) when a path leaves the volume (the line the reference
                                      comments out, pathtracer.cu:233).  default 0 = reference behaviour */
-#define SVR_OPT_KERNEL 2          /* 0 auto, 1 pixel-per-thread kernel, 2 persistent regenerating kernel */
+#define SVR_OPT_KERNEL 2          /* 0 auto (= 2); 1 one block per 16x16 tile (reference-shaped baseline);
+                                     2 persistent waves, one 8x8 tile-task per wave, empty-space skipping (default);
+                                     3 persistent waves with per-lane state machine and ballot/mbcnt lane regeneration */
 #define SVR_OPT_COUNT 3           /* 1: count volume taps etc. (slower; for roofline accounting) */
 #define SVR_OPT_TIMING 4          /* 1: bracket the path-tracing kernel with HIP events */
 #define SVR_OPT_SKIP_TONEMAP 5    /* 1: render_pathtracer does not run hdr_to_ldr (batch rendering) */
@@ -186,6 +188,8 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
 #define SVR_OPT_PIPELINE 7        /* 1 (default): trace kernels of consecutive frame groups run on internal streams
                                      and overlap; the accumulator is still updated in frame order on the caller's
                                      stream.  0: everything on the caller's stream */
+#define SVR_OPT_EMPTY_SKIP 9       /* 1 (default): skip the voxel fetches of Woodcock iterations in macro-cells where the
+                                     transfer function is exactly transparent (bit-identical results; RNG still advanced) */
 #define SVR_OPT_REFILL_MIN_IDLE 8 /* persistent kernel: regenerate lanes once this many of a wave's 64 lanes are idle
                                      (64 = a wave finishes its 8x8 tile before taking the next; default) */
 int svr_set_option(int key, int value);
@@ -200,13 +204,13 @@ int svr_hdr_to_ldr(void* img, const svr_render_params* renderParams);
 
 typedef struct svr_counters {
     uint64_t paths;
-    uint64_t vol_taps;         /* 8-voxel trilinear fetches */
+    uint64_t vol_taps;         /* 8-voxel trilinear fetches of the algorithm (what the reference issues) */
     uint64_t woodcock_iters;
     uint64_t scatter_events;
     uint64_t shadow_walks;
     uint64_t raycast_steps;
-    uint64_t loop_iters;       /* persistent kernel: wave-level scheduler iterations */
-    uint64_t reserved;
+    uint64_t loop_iters;       /* persistent kernels: wave-level scheduler iterations / tile tasks */
+    uint64_t vol_taps_executed; /* fetches actually issued (<= vol_taps: empty-space skipping, reused scatter tap) */
 } svr_counters;
 int svr_get_counters(svr_counters* out);              /* synchronises the launch stream */
 int svr_reset_counters(void);

@@ -19,8 +19,8 @@ LIB_PATH = Path(os.environ["SVR_HIP_LIB"]) if os.environ.get("SVR_HIP_LIB") else
 ORACLE_DIR = REPO_ROOT / "oracle"
 ORACLE_LIB = ORACLE_DIR / "libsvr_oracle.so"
 
-HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip"]
-HIP_HEADERS = ["svr_math.hpp", "svr_scene.hpp", "svr_device.hpp", "svr_kernels.hpp"]
+HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_accel.hip"]
+HIP_HEADERS = ["svr_math.hpp", "svr_scene.hpp", "svr_device.hpp", "svr_kernels.hpp", "svr_kernel_common.hpp"]
 
 HIPCC_FLAGS = [
     "-O3",

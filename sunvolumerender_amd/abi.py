@@ -101,11 +101,11 @@ class Counters(C.Structure):  # svr_counters
         ("shadow_walks", C.c_uint64),
         ("raycast_steps", C.c_uint64),
         ("loop_iters", C.c_uint64),
-        ("reserved", C.c_uint64),
+        ("vol_taps_executed", C.c_uint64),
     ]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ }
 
 
 EXPECTED_SIZES = {
@@ -128,8 +128,8 @@ TF_TABLE_SIZE = 1024
 
 LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_BRICK = 0, 1, 2
 OPT_ENV_ON_ESCAPE, OPT_KERNEL, OPT_COUNT, OPT_TIMING, OPT_SKIP_TONEMAP, OPT_BLOCKS_PER_CU = 1, 2, 3, 4, 5, 6
-OPT_PIPELINE, OPT_REFILL_MIN_IDLE = 7, 8
-KERNEL_AUTO, KERNEL_PIXEL, KERNEL_PERSISTENT = 0, 1, 2
+OPT_PIPELINE, OPT_REFILL_MIN_IDLE, OPT_EMPTY_SKIP = 7, 8, 9
+KERNEL_AUTO, KERNEL_PIXEL, KERNEL_TILE, KERNEL_ULOOP = 0, 1, 2, 3
 
 # every symbol include/svr_abi.h declares: name -> (restype, argtypes)
 _P = C.POINTER

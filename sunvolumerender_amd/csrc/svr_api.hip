@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 static_assert(sizeof(svr_vec3) == 12, "glm::vec3 layout");
 static_assert(sizeof(svr_bbox) == 36, "cudaBBox layout");
@@ -44,6 +45,12 @@ struct Texture {
     int layout;
     int sy, sz, bnx, bny;
     size_t bytes;
+    // volume: per-macro-cell min/max of the raw voxels (empty-space skipping)
+    uint16_t* mm = nullptr;
+    int mc_shift = 0, mc_gx = 0, mc_gy = 0, mc_gz = 0;
+    // transfer function: prefix count of exactly-zero alphas of the padded table, and an edit counter
+    uint32_t* zero_prefix = nullptr;
+    uint64_t version = 0;
 };
 constexpr uint32_t TEX_MAGIC = 0x53565254u;   // "SVRT"
 
@@ -82,7 +89,13 @@ struct Context {
     } sets[NSETS];
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 64;
+    int opt_pipeline = 1, opt_refill = 64, opt_empty_skip = 1;
+    // empty-space bitmask of the current (volume, transfer function, densityScale)
+    uint32_t* d_mask = nullptr;
+    bool mask_valid = false;
+    uint64_t mask_vol = 0, mask_tf = 0, mask_tf_version = 0;
+    uint32_t mask_ds_bits = 0;
+    uint32_t mask_words = 0;
     // ring of HIP event pairs around the path-tracing kernel (SVR_OPT_TIMING); drained lazily so the
     // timed launches never synchronise with the host
     static constexpr int EV_RING = 512;
@@ -144,6 +157,7 @@ int ensure_init()
     HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
     HIP_TRY(hipMalloc((void**)&g.d_ticket, 64 * Context::NSETS));
     HIP_TRY(hipMemset(g.d_ticket, 0, 64 * Context::NSETS));
+    HIP_TRY(hipMalloc((void**)&g.d_mask, svr::MASK_WORDS_MAX * sizeof(uint32_t)));
     for (int i = 0; i < Context::NSETS; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&g.sets[i].stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&g.sets[i].traced, hipEventDisableTiming));
@@ -318,6 +332,36 @@ void collect_timing()
     }
 }
 
+// (Re)build the empty-space bitmask when the volume, the transfer-function table or densityScale
+// changed.  Scene edits are rare (UI events), so the rebuild simply drains the device first.
+int ensure_mask(svr::DevScene& s)
+{
+    s.empty_mask = nullptr;
+    if (!g.opt_empty_skip) return 0;
+    Texture* tv = find_tex(g.vol.tex, TEX_VOLUME);
+    Texture* tt = find_tex(g.tf.tex, TEX_TF);
+    if (!tv || !tt || !tv->mm || !tt->zero_prefix) return 0;
+    uint32_t ds_bits;
+    memcpy(&ds_bits, &g.vol.densityScale, 4);
+    uint32_t n_cells = (uint32_t)tv->mc_gx * (uint32_t)tv->mc_gy * (uint32_t)tv->mc_gz;
+    uint32_t words = (n_cells + 31u) / 32u;
+    if (!(g.mask_valid && g.mask_vol == g.vol.tex && g.mask_tf == g.tf.tex && g.mask_tf_version == tt->version &&
+          g.mask_ds_bits == ds_bits)) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(svr::launch_empty_mask(tv->mm, n_cells, tt->zero_prefix, tt->nx, g.vol.densityScale, g.d_mask,
+                                       svr::MASK_WORDS_MAX, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        g.mask_valid = true; g.mask_vol = g.vol.tex; g.mask_tf = g.tf.tex; g.mask_tf_version = tt->version;
+        g.mask_ds_bits = ds_bits; g.mask_words = words;
+    }
+    s.empty_mask = g.d_mask;
+    s.mask_words = g.mask_words;
+    s.mc_shift = tv->mc_shift;
+    s.mc_gx = tv->mc_gx;
+    s.mc_gxy = tv->mc_gx * tv->mc_gy;
+    return 0;
+}
+
 int ensure_slots(uint32_t W, uint32_t H)
 {
     size_t need = (size_t)3 * W * H;
@@ -346,7 +390,8 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     if ((size_t)3 * s.imageW * s.imageH >= ((size_t)1 << 32)) return fail(-3, "image too large");
     if (ensure_slots(s.imageW, s.imageH)) return g.err_code;
     svr::LaunchCfg cfg;
-    cfg.kernel = g.opt_kernel == svr::KERNEL_AUTO ? svr::KERNEL_PERSISTENT : g.opt_kernel;
+    cfg.kernel = g.opt_kernel == svr::KERNEL_AUTO ? svr::KERNEL_TILE : g.opt_kernel;
+    if (cfg.kernel == svr::KERNEL_TILE && ensure_mask(s)) return g.err_code;
     cfg.count = g.opt_count != 0;
     cfg.num_cus = g.num_cus;
     cfg.blocks_per_cu = g.opt_blocks_per_cu > 0 ? g.opt_blocks_per_cu : 4;
@@ -375,7 +420,8 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
             slot = g.ev_head;
             HIP_TRY(hipEventRecord(g.ev0[slot], ts));
         }
-        HIP_TRY(svr::launch_pathtrace(s, w, cfg, ts));
+        if (cfg.kernel == svr::KERNEL_TILE) HIP_TRY(svr::launch_trace_tile(s, w, cfg, ts));
+        else HIP_TRY(svr::launch_pathtrace(s, w, cfg, ts));
         if (g.opt_timing) {
             HIP_TRY(hipEventRecord(g.ev1[slot], ts));
             g.ev_head = (g.ev_head + 1) % Context::EV_RING;
@@ -415,6 +461,8 @@ void svr_shutdown(void)
     hipDeviceSynchronize();
     for (auto& kv : g.textures) {
         if (kv.second->data) hipFree(kv.second->data);
+        if (kv.second->mm) hipFree(kv.second->mm);
+        if (kv.second->zero_prefix) hipFree(kv.second->zero_prefix);
         delete kv.second;
     }
     g.textures.clear();
@@ -424,6 +472,7 @@ void svr_shutdown(void)
         if (st.traced) hipEventDestroy(st.traced);
         if (st.resolved) hipEventDestroy(st.resolved);
     }
+    if (g.d_mask) hipFree(g.d_mask);
     if (g.d_counters) hipFree(g.d_counters);
     if (g.d_ticket) hipFree(g.d_ticket);
     for (int i = 0; i < Context::EV_RING; ++i) {
@@ -464,8 +513,15 @@ uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int n
 {
     if (ensure_init()) return 0;
     if (!voxels || nx <= 0 || ny <= 0 || nz <= 0) { fail(-6, "svr_create_volume_texture: bad arguments (%p, %d, %d, %d)", (const void*)voxels, nx, ny, nz); return 0; }
-    if (layout == SVR_LAYOUT_AUTO) layout = SVR_LAYOUT_LINEAR;
-    if (layout != SVR_LAYOUT_LINEAR && layout != SVR_LAYOUT_BRICK) { fail(-6, "svr_create_volume_texture: unknown layout %d", layout); return 0; }
+    if (layout != SVR_LAYOUT_AUTO && layout != SVR_LAYOUT_LINEAR && layout != SVR_LAYOUT_BRICK) { fail(-6, "svr_create_volume_texture: unknown layout %d", layout); return 0; }
+    {
+        // BRICK needs 24-bit brick-row / brick-slab strides (svr_trace_tile.hip); AUTO picks it when they fit
+        size_t bx = ((size_t)nx + 2 * svr::VOL_PAD + svr::BRICK_X - 1) / svr::BRICK_X;
+        size_t by = ((size_t)ny + 2 * svr::VOL_PAD + svr::BRICK_Y - 1) / svr::BRICK_Y;
+        bool brick_ok = (bx * by * 256) < ((size_t)1 << 24);
+        if (layout == SVR_LAYOUT_AUTO) layout = brick_ok ? SVR_LAYOUT_BRICK : SVR_LAYOUT_LINEAR;
+        if (layout == SVR_LAYOUT_BRICK && !brick_ok) { fail(-6, "svr_create_volume_texture: %dx%d slices are too large for the BRICK layout; use LINEAR", nx, ny); return 0; }
+    }
     Texture* t = new Texture();
     t->magic = TEX_MAGIC; t->kind = TEX_VOLUME; t->nx = nx; t->ny = ny; t->nz = nz; t->layout = layout;
     size_t px = (size_t)nx + 2 * svr::VOL_PAD, py = (size_t)ny + 2 * svr::VOL_PAD, pz = (size_t)nz + 2 * svr::VOL_PAD;
@@ -478,7 +534,15 @@ uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int n
         t->bnx = (int)bx; t->bny = (int)by; t->sy = 0; t->sz = 0;
         elems = bx * by * bz * (size_t)(svr::BRICK_X * svr::BRICK_Y * svr::BRICK_Z);
     }
-    if (elems >= ((size_t)1 << 31)) { delete t; fail(-6, "svr_create_volume_texture: %zu padded voxels exceed 32-bit element indexing", elems); return 0; }
+    if (elems >= ((size_t)1 << 31)) { delete t; fail(-6, "svr_create_volume_texture: %zu padded voxels exceed 32-bit byte offsets", elems); return 0; }
+    // macro-cell grid for empty-space skipping: smallest cell size whose bitmask fits MASK_WORDS_MAX words
+    {
+        int sh = 0;
+        for (;; ++sh) {
+            size_t gx = (((size_t)nx - 1) >> sh) + 1, gy = (((size_t)ny - 1) >> sh) + 1, gz = (((size_t)nz - 1) >> sh) + 1;
+            if (gx * gy * gz <= (size_t)svr::MASK_WORDS_MAX * 32) { t->mc_shift = sh; t->mc_gx = (int)gx; t->mc_gy = (int)gy; t->mc_gz = (int)gz; break; }
+        }
+    }
     t->bytes = elems * sizeof(uint16_t);
     size_t src_bytes = (size_t)nx * ny * nz * sizeof(uint16_t);
     const uint16_t* d_src = voxels;
@@ -493,9 +557,11 @@ uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int n
     e = hipMalloc(&t->data, t->bytes);
     if (e == hipSuccess) e = hipMemsetAsync(t->data, 0, t->bytes, g.stream);
     if (e == hipSuccess) e = svr::launch_repack(d_src, (uint16_t*)t->data, nx, ny, nz, layout, t->sy, t->sz, t->bnx, t->bny, g.stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->mm, (size_t)t->mc_gx * t->mc_gy * t->mc_gz * 2 * sizeof(uint16_t));
+    if (e == hipSuccess) e = svr::launch_minmax(d_src, t->mm, nx, ny, nz, t->mc_shift, t->mc_gx, t->mc_gy, t->mc_gz, g.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
     if (staged) hipFree(staged);
-    if (e != hipSuccess) { if (t->data) hipFree(t->data); delete t; fail((int)e, "volume texture creation failed: %s", hipGetErrorName(e)); return 0; }
+    if (e != hipSuccess) { if (t->data) hipFree(t->data); if (t->mm) hipFree(t->mm); delete t; fail((int)e, "volume texture creation failed: %s", hipGetErrorName(e)); return 0; }
     uint64_t h = (uint64_t)(uintptr_t)t;
     g.textures[h] = t;
     return h;
@@ -516,10 +582,35 @@ static uint64_t create_float4_texture(int kind, const float* rgba, int w, int h,
     return hd;
 }
 
+// zero_prefix[e] = number of entries < e of the padded alpha table (entry e = alpha of texel clamp(e-1),
+// e in [0, n+2]) that are exactly zero; n+4 words
+static int upload_zero_prefix(Texture* t)
+{
+    int n = t->nx;
+    std::vector<float> host((size_t)n * 4);
+    hipError_t e = hipMemcpy(host.data(), t->data, host.size() * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail((int)e, "transfer-function read-back failed: %s", hipGetErrorName(e));
+    std::vector<uint32_t> pre((size_t)n + 4, 0u);
+    for (int k = 0; k < n + 3; ++k) {
+        int tex = k - 1 < 0 ? 0 : (k - 1 > n - 1 ? n - 1 : k - 1);
+        pre[(size_t)k + 1] = pre[(size_t)k] + (host[(size_t)tex * 4 + 3] == 0.f ? 1u : 0u);
+    }
+    if (!t->zero_prefix) {
+        e = hipMalloc((void**)&t->zero_prefix, pre.size() * sizeof(uint32_t));
+        if (e != hipSuccess) return fail((int)e, "hipMalloc failed: %s", hipGetErrorName(e));
+    }
+    e = hipMemcpy(t->zero_prefix, pre.data(), pre.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail((int)e, "zero-prefix upload failed: %s", hipGetErrorName(e));
+    t->version++;
+    return 0;
+}
+
 uint64_t svr_create_tf_texture(const float* rgba, int n, int src_is_device)
 {
     if (n > SVR_TF_TABLE_SIZE) { ensure_init(); fail(-6, "transfer-function table of %d entries exceeds the LDS-resident limit of %d", n, SVR_TF_TABLE_SIZE); return 0; }
-    return create_float4_texture(TEX_TF, rgba, n, 1, src_is_device);
+    uint64_t h = create_float4_texture(TEX_TF, rgba, n, 1, src_is_device);
+    if (h && upload_zero_prefix(find_tex(h, TEX_TF))) return 0;
+    return h;
 }
 
 int svr_update_tf_texture(uint64_t handle, const float* rgba, int n, int src_is_device)
@@ -530,7 +621,7 @@ int svr_update_tf_texture(uint64_t handle, const float* rgba, int n, int src_is_
     if (n != t->nx || !rgba) return fail(-6, "svr_update_tf_texture: size mismatch (%d vs %d)", n, t->nx);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(t->data, rgba, t->bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    return 0;
+    return upload_zero_prefix(t);
 }
 
 uint64_t svr_create_env_texture(const float* rgba, int w, int h, int src_is_device)
@@ -546,6 +637,9 @@ int svr_destroy_texture(uint64_t handle)
     HIP_TRY(hipDeviceSynchronize());
     Texture* t = it->second;
     if (t->data) hipFree(t->data);
+    if (t->mm) hipFree(t->mm);
+    if (t->zero_prefix) hipFree(t->zero_prefix);
+    if (g.mask_vol == handle || g.mask_tf == handle) g.mask_valid = false;
     t->magic = 0;
     delete t;
     g.textures.erase(it);
@@ -685,7 +779,7 @@ int svr_set_option(int key, int value)
     switch (key) {
     case SVR_OPT_ENV_ON_ESCAPE: g.opt_env_on_escape = value ? 1 : 0; return 0;
     case SVR_OPT_KERNEL:
-        if (value < 0 || value > 2) return fail(-6, "SVR_OPT_KERNEL: bad value %d", value);
+        if (value < 0 || value > 3) return fail(-6, "SVR_OPT_KERNEL: bad value %d", value);
         g.opt_kernel = value; return 0;
     case SVR_OPT_COUNT: g.opt_count = value ? 1 : 0; return 0;
     case SVR_OPT_TIMING: g.opt_timing = value ? 1 : 0; return 0;
@@ -694,6 +788,7 @@ int svr_set_option(int key, int value)
         if (value < 0 || value > 8) return fail(-6, "SVR_OPT_BLOCKS_PER_CU: bad value %d", value);
         g.opt_blocks_per_cu = value; return 0;
     case SVR_OPT_PIPELINE: g.opt_pipeline = value ? 1 : 0; return 0;
+    case SVR_OPT_EMPTY_SKIP: g.opt_empty_skip = value ? 1 : 0; return 0;
     case SVR_OPT_REFILL_MIN_IDLE:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_REFILL_MIN_IDLE: bad value %d (1..64)", value);
         g.opt_refill = value; return 0;
@@ -711,6 +806,7 @@ int svr_get_option(int key)
     case SVR_OPT_SKIP_TONEMAP: return g.opt_skip_tonemap;
     case SVR_OPT_BLOCKS_PER_CU: return g.opt_blocks_per_cu;
     case SVR_OPT_PIPELINE: return g.opt_pipeline;
+    case SVR_OPT_EMPTY_SKIP: return g.opt_empty_skip;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     default: return -1;
     }

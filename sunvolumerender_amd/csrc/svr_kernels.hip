@@ -2,7 +2,7 @@
 //
 //  k_pathtrace_pixel       one thread per pixel, the shape of the reference's kernel_pathtracer
 //                          (pathtracer.cu:200-280).  Baseline / debugging kernel.
-//  k_pathtrace_persistent  MI355X-first kernel: persistent waves, every lane is a small state
+//  k_pathtrace_uloop  MI355X-first kernel: persistent waves, every lane is a small state
 //                          machine that owns one path at a time; all volume fetches of all
 //                          stages (primary Woodcock walk, gradient taps, shadow Woodcock walk)
 //                          go through ONE shared tap site per scheduler iteration, lanes that
@@ -13,118 +13,9 @@
 //  k_tonemap               hdr_to_ldr (pathtracer.cu:282-290)
 //  k_raycast               kernel_raycasting (raycasting.cu:15-67)
 //  k_repack_*              [z][y][x] u16 -> padded LINEAR / BRICK software-texture layouts
-#include "svr_kernels.hpp"
-#include "svr_device.hpp"
+#include "svr_kernel_common.hpp"
 
 namespace svr {
-
-#define SVR_TF_MAX 1024
-// Hang guard, not part of the algorithm: a single Woodcock walk is abandoned (treated as leaving the
-// volume) after 2^20 iterations.  Unreachable for sane scenes (expected iterations = sigma_max x chord
-// length, ~10^2..10^3); it only bounds kernels fed degenerate majorants so a launch always drains.
-#define SVR_WALK_GUARD (1u << 20)
-#define SVR_TF_PAD 3
-
-// ------------------------------------------------------------------------------------------
-// LDS-resident transfer function.  Entry e of the padded tables holds texel clamp(e-1), so the
-// clamp addressing of tex1D becomes plain adjacent reads (ds_read2_b32 for the alpha pair).
-// ------------------------------------------------------------------------------------------
-struct LdsTF {
-    float4 rgba[SVR_TF_MAX + SVR_TF_PAD];
-    float alpha[SVR_TF_MAX + SVR_TF_PAD];
-};
-
-SVR_DEV void lds_tf_load(LdsTF& L, const DevScene& s)
-{
-    const int n = s.tf_n;
-    const float4* g = reinterpret_cast<const float4*>(s.tf);
-    for (int e = threadIdx.x; e < n + SVR_TF_PAD; e += blockDim.x) {
-        int t = min(max(e - 1, 0), n - 1);
-        float4 v = g[t];
-        L.rgba[e] = v;
-        L.alpha[e] = v.w;
-    }
-    __syncthreads();
-}
-
-SVR_DEV void lds_tf_coord(const DevScene& s, float x, int& e, float& a)
-{
-    float xb = fma_(x, s.tf_nf, -0.5f);
-    xb = fmin_(fmax_(xb, -1.f), s.tf_nf);
-    float fx = __builtin_floorf(xb);
-    a = xb - fx;
-    e = (int)fx + 1;          // in [0, n+1]
-}
-
-SVR_DEV float lds_tf_alpha(const LdsTF& L, const DevScene& s, float x)
-{
-    int e; float a;
-    lds_tf_coord(s, x, e, a);
-    float t0 = L.alpha[e], t1 = L.alpha[e + 1];
-    return lerpf(t0, t1, a);
-}
-
-SVR_DEV void lds_tf_rgba(const LdsTF& L, const DevScene& s, float x, float out[4])
-{
-    int e; float a;
-    lds_tf_coord(s, x, e, a);
-    float4 t0 = L.rgba[e], t1 = L.rgba[e + 1];
-    out[0] = lerpf(t0.x, t1.x, a);
-    out[1] = lerpf(t0.y, t1.y, a);
-    out[2] = lerpf(t0.z, t1.z, a);
-    out[3] = lerpf(t0.w, t1.w, a);
-}
-
-// ------------------------------------------------------------------------------------------
-// pixel enumeration: owned rows (window or interleaved row strips), 8x8 tiles, 64 items per tile
-// ------------------------------------------------------------------------------------------
-SVR_DEV uint32_t owned_row_to_y(const DevWork& w, uint32_t r)
-{
-    if (w.world <= 1u) return w.y0 + r;
-    uint32_t q = r / w.strip_rows;
-    return (q * w.world + w.rank) * w.strip_rows + (r - q * w.strip_rows);
-}
-
-// item -> (pixel, frame slot).  Items enumerate wave-tasks tile-major: task = tile * nframes + slot,
-// 64 items (one 8x8 tile) per task, so concurrently running waves work on neighbouring tubes of the
-// volume.  false for the padding items of partial tiles.
-SVR_DEV bool item_to_pixel(const DevWork& w, uint32_t item, uint32_t& x, uint32_t& y, uint32_t& slot)
-{
-    uint32_t wv = w.x1 - w.x0;
-    uint32_t tiles_x = (wv + 7u) >> 3;
-    uint32_t task = item >> 6, in = item & 63u;
-    uint32_t tile = task / w.nframes;
-    slot = task - tile * w.nframes;
-    uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    uint32_t px = (tx << 3) + (in & 7u);
-    uint32_t r = (ty << 3) + (in >> 3);
-    if (px >= wv || r >= w.n_rows) return false;
-    x = w.x0 + px;
-    y = owned_row_to_y(w, r);
-    return true;
-}
-
-SVR_DEV unsigned long long wave_sum(unsigned long long v)
-{
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-struct Cnt { uint32_t taps, iters, scatter, shadow, paths, loops; };
-
-SVR_DEV void cnt_flush(const DevWork& w, const Cnt& c)
-{
-    unsigned long long a = wave_sum(c.taps), b = wave_sum(c.iters), d = wave_sum(c.scatter),
-                       e = wave_sum(c.shadow), f = wave_sum(c.paths);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&w.counters[CNT_VOL_TAPS], a);
-        atomicAdd(&w.counters[CNT_WOODCOCK], b);
-        atomicAdd(&w.counters[CNT_SCATTER], d);
-        atomicAdd(&w.counters[CNT_SHADOW], e);
-        atomicAdd(&w.counters[CNT_PATHS], f);
-        atomicAdd(&w.counters[CNT_LOOP], (unsigned long long)c.loops);
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // Baseline: straight transcription of one path (pathtracer.cu:205-277)
@@ -144,7 +35,7 @@ SVR_DEV float sample_distance(const DevScene& s, const LdsTF& tf, v3 orig, v3 di
             t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
             if (t > tMax || guard >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
             v3 p = orig + dir * t;
-            if (COUNT) c.taps++;
+            if (COUNT) { c.taps++; c.exec++; }
             float intensity = volume_intensity<LAYOUT>(s, p);
             float sigma_t = lds_tf_alpha(tf, s, intensity);
             if (rng_uniform(rng) < sigma_t * s.invSigmaMax) break;
@@ -184,7 +75,7 @@ SVR_DEV v3 trace_path(const DevScene& s, const LdsTF& tf, uint32_t x, uint32_t y
             break;
         }
         Shade vs;
-        if (COUNT) { c.scatter++; c.taps += 7; }
+        if (COUNT) { c.scatter++; c.taps += 7; c.exec += 7; }
         vs.wo = -dir;
         vs.pt = orig + dir * t;
         float intensity = volume_intensity<LAYOUT>(s, vs.pt);
@@ -234,7 +125,7 @@ __global__ __launch_bounds__(256, SVR_WAVES_PER_EU_PIXEL) void k_pathtrace_pixel
 {
     __shared__ LdsTF tf;
     lds_tf_load(tf, s);
-    Cnt c = {0, 0, 0, 0, 0, 0};
+    Cnt c = {0, 0, 0, 0, 0, 0, 0};
     // one (16x16 pixel tile, frame slot) per block, one 8x8 sub-tile per wave
     uint32_t wv = w.x1 - w.x0;
     uint32_t tiles16_x = (wv + 15u) >> 4;
@@ -262,7 +153,7 @@ enum : uint32_t { S_IDLE = 0, S_START, S_WALK, S_GRAD, S_SHADE, S_SCATTER, S_FIN
 #define SVR_WAVES_PER_EU 4
 #endif
 template <int LAYOUT, bool COUNT>
-__global__ __launch_bounds__(256, SVR_WAVES_PER_EU) void k_pathtrace_persistent(const DevScene s, const DevWork w)
+__global__ __launch_bounds__(256, SVR_WAVES_PER_EU) void k_pathtrace_uloop(const DevScene s, const DevWork w)
 {
     __shared__ LdsTF tf;
     lds_tf_load(tf, s);
@@ -272,7 +163,7 @@ __global__ __launch_bounds__(256, SVR_WAVES_PER_EU) void k_pathtrace_persistent(
     const uint32_t n_tiles = ((wv + 7u) >> 3) * ((w.n_rows + 7u) >> 3);
     const uint32_t total_items = (n_tiles * w.nframes) << 6;
 
-    Cnt c = {0, 0, 0, 0, 0, 0};
+    Cnt c = {0, 0, 0, 0, 0, 0, 0};
 
     // wave-uniform work range
     uint32_t it_next = 0, it_end = 0;
@@ -466,7 +357,7 @@ __global__ __launch_bounds__(256, SVR_WAVES_PER_EU) void k_pathtrace_persistent(
         float val = 0.f;
         if (__ballot(tapping) != 0ull) {
             if (tapping) {
-                if (COUNT) c.taps++;
+                if (COUNT) { c.taps++; c.exec++; }
                 val = volume_intensity<LAYOUT>(s, p);
                 if (state == S_WALK) {
                     // woodcock_tracking.h:40-44
@@ -511,7 +402,7 @@ __global__ __launch_bounds__(256, SVR_WAVES_PER_EU) void k_pathtrace_persistent(
             if (done) state = S_FINISH;
             else {
                 // VolumeSample: the collision point is the last Woodcock tap, so its intensity is `val`
-                if (COUNT) c.scatter++;
+                if (COUNT) { c.scatter++; c.taps++; }
                 vs.wo = -d;
                 vs.pt = p;
                 lds_tf_rgba(tf, s, val, vs.color);
@@ -671,7 +562,7 @@ static hipError_t launch_pathtrace_t(const DevScene& s, const DevWork& w, const 
         if (blocks == 0) blocks = 1;
         hipError_t e = hipMemsetAsync(w.ticket, 0, sizeof(uint32_t), st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_pathtrace_persistent<LAYOUT, COUNT>), dim3(blocks), dim3(256), 0, st, s, w);
+        hipLaunchKernelGGL((k_pathtrace_uloop<LAYOUT, COUNT>), dim3(blocks), dim3(256), 0, st, s, w);
     }
     return hipGetLastError();
 }

@@ -6,10 +6,11 @@
 
 namespace svr {
 
-enum { KERNEL_AUTO = 0, KERNEL_PIXEL = 1, KERNEL_PERSISTENT = 2 };
+enum { KERNEL_AUTO = 0, KERNEL_PIXEL = 1, KERNEL_TILE = 2, KERNEL_ULOOP = 3 };
+constexpr uint32_t MASK_WORDS_MAX = 8192;   // 32 KiB of LDS: 64^3 macro-cells
 
 // counter slots (unsigned long long each) -- order of svr_counters in include/svr_abi.h
-enum { CNT_PATHS = 0, CNT_VOL_TAPS, CNT_WOODCOCK, CNT_SCATTER, CNT_SHADOW, CNT_RAYCAST, CNT_LOOP, CNT_RESERVED, CNT_N };
+enum { CNT_PATHS = 0, CNT_VOL_TAPS, CNT_WOODCOCK, CNT_SCATTER, CNT_SHADOW, CNT_RAYCAST, CNT_LOOP, CNT_TAPS_EXEC, CNT_N };
 
 struct LaunchCfg {
     int kernel;            // KERNEL_*
@@ -22,6 +23,13 @@ struct LaunchCfg {
 hipError_t launch_pathtrace(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
 // fold the scratch slots into the running mean (frame order) and, if work.img, tone-map
 hipError_t launch_resolve(const DevScene& scene, const DevWork& work, hipStream_t stream);
+// default trace kernel (svr_trace_tile.hip): persistent waves, one 8x8 tile-task per wave, empty-space skipping
+hipError_t launch_trace_tile(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
+// acceleration data (svr_accel.hip): per-macro-cell min/max of the raw voxels, and the empty bitmask
+hipError_t launch_minmax(const uint16_t* src_linear, uint16_t* mm, int nx, int ny, int nz, int shift,
+                         int gx, int gy, int gz, hipStream_t stream);
+hipError_t launch_empty_mask(const uint16_t* mm, uint32_t n_cells, const uint32_t* tf_zero_prefix, int tf_n,
+                             float densityScale, uint32_t* mask, uint32_t mask_words, hipStream_t stream);
 // hdr_to_ldr over the owned pixels
 hipError_t launch_tonemap(const DevScene& scene, const DevWork& work, hipStream_t stream);
 // kernel_raycasting over the owned pixels

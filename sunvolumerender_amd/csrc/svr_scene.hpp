@@ -39,6 +39,11 @@ struct DevScene {
     float fnx, fny, fnz;
     int32_t sy, sz;                // LINEAR: element strides of the padded array
     int32_t bnx, bny;              // BRICK: bricks per row / per slab-row
+    // empty-space bitmask (one bit per macro-cell of 2^mc_shift cells per axis; bit set = every
+    // trilinear fetch whose cell lies in the macro-cell has transfer-function alpha exactly 0)
+    const uint32_t* empty_mask;    // device, mask_words words, or null (no skipping)
+    int32_t mc_shift, mc_gx, mc_gxy;
+    uint32_t mask_words;
     // ---- cudaTransferFunction ----
     const float* tf;               // tf_n x float4
     int32_t tf_n;

@@ -20,13 +20,15 @@ def oracle_frames(scene, nframes, trace_depth=None, window=None, nthreads=0):
 
 
 def hip_frames(dev, scene, nframes, kernel=abi.KERNEL_AUTO, layout=abi.LAYOUT_AUTO, batch=False, count=True,
-               shard=None, window=None):
+               shard=None, window=None, empty_skip=True, pipeline=True):
     """Progressive frames 0..nframes-1 through libsvr_hip.so, replaying the Canvas protocol."""
     canvas = host.Canvas(dev, scene.width, scene.height)
     try:
         scenes.apply_to_canvas(scene, canvas, layout)
         dev.set_option(abi.OPT_KERNEL, kernel)
         dev.set_option(abi.OPT_COUNT, 1 if count else 0)
+        dev.set_option(abi.OPT_EMPTY_SKIP, 1 if empty_skip else 0)
+        dev.set_option(abi.OPT_PIPELINE, 1 if pipeline else 0)
         if shard is not None:
             dev.check(dev.lib.svr_set_row_shard(*shard))
         if window is not None:
@@ -44,6 +46,8 @@ def hip_frames(dev, scene, nframes, kernel=abi.KERNEL_AUTO, layout=abi.LAYOUT_AU
         dev.lib.svr_set_render_window(0, 0, -1, -1)
         dev.set_option(abi.OPT_KERNEL, abi.KERNEL_AUTO)
         dev.set_option(abi.OPT_COUNT, 0)
+        dev.set_option(abi.OPT_EMPTY_SKIP, 1)
+        dev.set_option(abi.OPT_PIPELINE, 1)
         canvas.close()
     return hdr, img, counters
 

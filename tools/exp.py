@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing sweep over kernel options for one library build (select with SVR_HIP_LIB).
-usage: tools/exp.py [--scene c3] [--frames 16] combos...   combo = kernel,layout,bpc,refill,spp,pipeline"""
+usage: tools/exp.py [--scene c3] [--frames 16] combos...   combo = kernel,layout,bpc,refill,spp,pipeline,skip"""
 import argparse
 import ctypes as C
 import os
@@ -23,7 +23,7 @@ dev = host.Device(0)
 print("lib:", abi.library_path().name, "|", dev.info(), flush=True)
 canv = {}
 for combo in a.combos:
-    k, lay, bpc, refill, spp, pipe = [int(v) for v in combo.split(",")]
+    k, lay, bpc, refill, spp, pipe, skip = [int(v) for v in combo.split(",")]
     if lay not in canv:
         for c in canv.values():
             c.close()
@@ -36,6 +36,7 @@ for combo in a.combos:
     dev.set_option(abi.OPT_BLOCKS_PER_CU, bpc)
     dev.set_option(abi.OPT_REFILL_MIN_IDLE, refill)
     dev.set_option(abi.OPT_PIPELINE, pipe)
+    dev.set_option(abi.OPT_EMPTY_SKIP, skip)
     best = None
     for rep in range(3):
         c.ReStartRender()
@@ -51,7 +52,7 @@ for combo in a.combos:
         dev.synchronize()
         dt = (time.perf_counter() - t0) / n * 1e3
         best = dt if best is None else min(best, dt)
-    print(f"kernel={k} layout={lay} bpc={bpc} refill={refill:2d} spp/call={spp:2d} pipeline={pipe}:  {best:7.3f} ms/frame  "
+    print(f"kernel={k} layout={lay} bpc={bpc} refill={refill:2d} spp/call={spp:2d} pipeline={pipe} skip={skip}:  {best:7.3f} ms/frame  "
           f"{sc.width * sc.height / best / 1e3:8.1f} Msamples/s", flush=True)
 for c in canv.values():
     c.close()
