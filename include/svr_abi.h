@@ -190,6 +190,9 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
                                      stream.  0: everything on the caller's stream */
 #define SVR_OPT_EMPTY_SKIP 9       /* 1 (default): skip the voxel fetches of Woodcock iterations in macro-cells where the
                                      transfer function is exactly transparent (bit-identical results; RNG still advanced) */
+#define SVR_OPT_RAY_SKIP 10        /* 1 (default): per-ray conservative march over the dilated empty mask: a walk that can
+                                     never meet a non-transparent macro-cell ends at once when no random draw follows it,
+                                     and other walks skip cell tests up to their first possibly-occupied cell (bit-identical) */
 #define SVR_OPT_REFILL_MIN_IDLE 8 /* persistent kernel: regenerate lanes once this many of a wave's 64 lanes are idle
                                      (64 = a wave finishes its 8x8 tile before taking the next; default) */
 int svr_set_option(int key, int value);
@@ -211,6 +214,10 @@ typedef struct svr_counters {
     uint64_t raycast_steps;
     uint64_t loop_iters;       /* persistent kernels: wave-level scheduler iterations / tile tasks */
     uint64_t vol_taps_executed; /* fetches actually issued (<= vol_taps: empty-space skipping, reused scatter tap) */
+    uint64_t walks_ray_skipped; /* Woodcock walks a non-counting build ends at once (whole-ray test) */
+    uint64_t iters_ray_skipped; /* ... and the Woodcock iterations those walks contain */
+    uint64_t iters_prefix_skipped; /* iterations before a walk's first possibly-occupied macro-cell (no cell test) */
+    uint64_t reserved;
 } svr_counters;
 int svr_get_counters(svr_counters* out);              /* synchronises the launch stream */
 int svr_reset_counters(void);

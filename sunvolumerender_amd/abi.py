@@ -102,6 +102,10 @@ class Counters(C.Structure):  # svr_counters
         ("raycast_steps", C.c_uint64),
         ("loop_iters", C.c_uint64),
         ("vol_taps_executed", C.c_uint64),
+        ("walks_ray_skipped", C.c_uint64),
+        ("iters_ray_skipped", C.c_uint64),
+        ("iters_prefix_skipped", C.c_uint64),
+        ("reserved", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -118,7 +122,7 @@ EXPECTED_SIZES = {
     cudaAreaLight: 44,
     cudaEnvironmentLight: 32,
     RenderParams: 16,
-    Counters: 64,
+    Counters: 96,
 }
 for _t, _n in EXPECTED_SIZES.items():
     assert C.sizeof(_t) == _n, (_t, C.sizeof(_t), _n)
@@ -128,7 +132,7 @@ TF_TABLE_SIZE = 1024
 
 LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_BRICK = 0, 1, 2
 OPT_ENV_ON_ESCAPE, OPT_KERNEL, OPT_COUNT, OPT_TIMING, OPT_SKIP_TONEMAP, OPT_BLOCKS_PER_CU = 1, 2, 3, 4, 5, 6
-OPT_PIPELINE, OPT_REFILL_MIN_IDLE, OPT_EMPTY_SKIP = 7, 8, 9
+OPT_PIPELINE, OPT_REFILL_MIN_IDLE, OPT_EMPTY_SKIP, OPT_RAY_SKIP = 7, 8, 9, 10
 KERNEL_AUTO, KERNEL_PIXEL, KERNEL_TILE, KERNEL_ULOOP = 0, 1, 2, 3
 
 # every symbol include/svr_abi.h declares: name -> (restype, argtypes)

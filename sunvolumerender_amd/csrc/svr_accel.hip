@@ -2,7 +2,9 @@
 //
 // Macro-cell m (per axis, S = 2^shift) covers the trilinear cells c with c+1 in [m*S, m*S+S-1], i.e.
 // cells c in [m*S-1, m*S+S-2], whose 8-voxel footprints span voxels [m*S-1, m*S+S-1] (voxel -1 and
-// voxel N are border texels = 0).  k_minmax stores the min/max raw voxel value over that footprint.
+// voxel N are border texels = 0); the LAST macro-cell of an axis also takes cell c = N-1 (footprint up
+// to the border voxel N), so the grid covers every cell a point of the texture domain [0,1]^3 can map to.
+// k_minmax stores the min/max raw voxel value over that footprint.
 //
 // k_empty_mask marks a macro-cell empty iff the transfer-function alpha is exactly 0 for EVERY
 // intensity a fetch inside it can return.  Argument: each lerp fma(t, q-p, p) with t in [0,1) rounds
@@ -23,11 +25,12 @@ __global__ __launch_bounds__(64) void k_minmax(const uint16_t* __restrict__ src,
     int my = (int)((m / (uint32_t)gx) % (uint32_t)gy);
     int mz = (int)(m / ((uint32_t)gx * (uint32_t)gy));
     int x0 = mx * S - 1, y0 = my * S - 1, z0 = mz * S - 1;
-    int E = S + 1;                       // voxels per axis in the footprint
-    int total = E * E * E;
+    // voxels per axis in the footprint (+1 on the last macro-cell: border voxel N)
+    int Ex = S + 1 + (mx == gx - 1), Ey = S + 1 + (my == gy - 1), Ez = S + 1 + (mz == gz - 1);
+    int total = Ex * Ey * Ez;
     uint32_t lo = 0xffffu, hi = 0u;
     for (int e = threadIdx.x; e < total; e += 64) {
-        int dx = e % E, dy = (e / E) % E, dz = e / (E * E);
+        int dx = e % Ex, dy = (e / Ex) % Ey, dz = e / (Ex * Ey);
         int x = x0 + dx, y = y0 + dy, z = z0 + dz;
         uint32_t v = 0u;                 // border texel
         if (x >= 0 && y >= 0 && z >= 0 && x < nx && y < ny && z < nz)
@@ -76,13 +79,37 @@ hipError_t launch_minmax(const uint16_t* src, uint16_t* mm, int nx, int ny, int 
     return hipGetLastError();
 }
 
-hipError_t launch_empty_mask(const uint16_t* mm, uint32_t n_cells, const uint32_t* tf_zero_prefix, int tf_n,
+// deep-empty: the macro-cell and all its in-grid neighbours (3x3x3) are empty.  A ray marched through
+// the macro grid in float arithmetic can be off by far less than one macro-cell, so "every visited
+// cell is deep-empty" proves that every fetch along the ray lies in an empty macro-cell.
+__global__ __launch_bounds__(256) void k_deep_mask(const uint32_t* __restrict__ empty, uint32_t* __restrict__ deep,
+                                                   int gx, int gy, int gz)
+{
+    uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    uint32_t n = (uint32_t)gx * (uint32_t)gy * (uint32_t)gz;
+    if (m >= n) return;
+    int mx = (int)(m % (uint32_t)gx), my = (int)((m / (uint32_t)gx) % (uint32_t)gy), mz = (int)(m / ((uint32_t)gx * (uint32_t)gy));
+    bool all = true;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                int x = mx + dx, y = my + dy, z = mz + dz;
+                if (x < 0 || y < 0 || z < 0 || x >= gx || y >= gy || z >= gz) continue;
+                uint32_t q = (uint32_t)x + (uint32_t)gx * ((uint32_t)y + (uint32_t)gy * (uint32_t)z);
+                all = all && ((empty[q >> 5] >> (q & 31u)) & 1u);
+            }
+    if (all) atomicOr(&deep[m >> 5], 1u << (m & 31u));
+}
+
+hipError_t launch_empty_mask(const uint16_t* mm, int gx, int gy, int gz, const uint32_t* tf_zero_prefix, int tf_n,
                              float densityScale, uint32_t* mask, uint32_t mask_words, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(mask, 0, (size_t)mask_words * 4u, st);
+    uint32_t n_cells = (uint32_t)gx * (uint32_t)gy * (uint32_t)gz;
+    hipError_t e = hipMemsetAsync(mask, 0, (size_t)mask_words * 8u, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_empty_mask, dim3((n_cells + 255u) / 256u), dim3(256), 0, st, mm, n_cells,
-                       tf_zero_prefix, tf_n, densityScale, mask);
+                       tf_zero_prefix, tf_n, densityScale, mask + mask_words);
+    hipLaunchKernelGGL(k_deep_mask, dim3((n_cells + 255u) / 256u), dim3(256), 0, st, mask + mask_words, mask, gx, gy, gz);
     return hipGetLastError();
 }
 

@@ -89,7 +89,7 @@ struct Context {
     } sets[NSETS];
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 64, opt_empty_skip = 1;
+    int opt_pipeline = 1, opt_refill = 64, opt_empty_skip = 1, opt_ray_skip = 1;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     bool mask_valid = false;
@@ -157,7 +157,7 @@ int ensure_init()
     HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
     HIP_TRY(hipMalloc((void**)&g.d_ticket, 64 * Context::NSETS));
     HIP_TRY(hipMemset(g.d_ticket, 0, 64 * Context::NSETS));
-    HIP_TRY(hipMalloc((void**)&g.d_mask, svr::MASK_WORDS_MAX * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&g.d_mask, 2 * svr::MASK_WORDS_MAX * sizeof(uint32_t)));
     for (int i = 0; i < Context::NSETS; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&g.sets[i].stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&g.sets[i].traced, hipEventDisableTiming));
@@ -348,8 +348,8 @@ int ensure_mask(svr::DevScene& s)
     if (!(g.mask_valid && g.mask_vol == g.vol.tex && g.mask_tf == g.tf.tex && g.mask_tf_version == tt->version &&
           g.mask_ds_bits == ds_bits)) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(svr::launch_empty_mask(tv->mm, n_cells, tt->zero_prefix, tt->nx, g.vol.densityScale, g.d_mask,
-                                       svr::MASK_WORDS_MAX, g.stream));
+        HIP_TRY(svr::launch_empty_mask(tv->mm, tv->mc_gx, tv->mc_gy, tv->mc_gz, tt->zero_prefix, tt->nx,
+                                       g.vol.densityScale, g.d_mask, words, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
         g.mask_valid = true; g.mask_vol = g.vol.tex; g.mask_tf = g.tf.tex; g.mask_tf_version = tt->version;
         g.mask_ds_bits = ds_bits; g.mask_words = words;
@@ -357,8 +357,24 @@ int ensure_mask(svr::DevScene& s)
     s.empty_mask = g.d_mask;
     s.mask_words = g.mask_words;
     s.mc_shift = tv->mc_shift;
-    s.mc_gx = tv->mc_gx;
+    s.mc_gx = tv->mc_gx; s.mc_gy = tv->mc_gy; s.mc_gz = tv->mc_gz;
     s.mc_gxy = tv->mc_gx * tv->mc_gy;
+    // macro-grid coordinate of a world point: ((p - vmin) * invSize * N + 0.5) / S  (cell c' = c + 1)
+    float invS = 1.f / (float)(1 << tv->mc_shift);
+    s.mc_scale[0] = s.invSize[0] * s.fnx * invS;
+    s.mc_scale[1] = s.invSize[1] * s.fny * invS;
+    s.mc_scale[2] = s.invSize[2] * s.fnz * invS;
+    s.mc_off = 0.5f * invS;
+    // whole-ray tests need every fetch of a walk inside the texture domain: clipped box within the bbox
+    bool inside = true;
+    const float lo[3] = {g.vol.bbox.vmin.x, g.vol.bbox.vmin.y, g.vol.bbox.vmin.z};
+    const float hi[3] = {g.vol.bbox.vmax.x, g.vol.bbox.vmax.y, g.vol.bbox.vmax.z};
+    for (int a = 0; a < 3; ++a) {
+        float cl = s.clip_vmin[a] < s.clip_vmax[a] ? s.clip_vmin[a] : s.clip_vmax[a];
+        float ch = s.clip_vmin[a] < s.clip_vmax[a] ? s.clip_vmax[a] : s.clip_vmin[a];
+        inside = inside && cl >= lo[a] && ch <= hi[a] && lo[a] < hi[a];
+    }
+    s.ray_skip = (inside && g.opt_ray_skip) ? 1u : 0u;
     return 0;
 }
 
@@ -789,6 +805,7 @@ int svr_set_option(int key, int value)
         g.opt_blocks_per_cu = value; return 0;
     case SVR_OPT_PIPELINE: g.opt_pipeline = value ? 1 : 0; return 0;
     case SVR_OPT_EMPTY_SKIP: g.opt_empty_skip = value ? 1 : 0; return 0;
+    case SVR_OPT_RAY_SKIP: g.opt_ray_skip = value ? 1 : 0; return 0;
     case SVR_OPT_REFILL_MIN_IDLE:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_REFILL_MIN_IDLE: bad value %d (1..64)", value);
         g.opt_refill = value; return 0;
@@ -807,6 +824,7 @@ int svr_get_option(int key)
     case SVR_OPT_BLOCKS_PER_CU: return g.opt_blocks_per_cu;
     case SVR_OPT_PIPELINE: return g.opt_pipeline;
     case SVR_OPT_EMPTY_SKIP: return g.opt_empty_skip;
+    case SVR_OPT_RAY_SKIP: return g.opt_ray_skip;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     default: return -1;
     }

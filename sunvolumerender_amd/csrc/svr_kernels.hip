@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, SVR_WAVES_PER_EU_PIXEL) void k_pathtrace_pixel
 {
     __shared__ LdsTF tf;
     lds_tf_load(tf, s);
-    Cnt c = {0, 0, 0, 0, 0, 0, 0};
+    Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // one (16x16 pixel tile, frame slot) per block, one 8x8 sub-tile per wave
     uint32_t wv = w.x1 - w.x0;
     uint32_t tiles16_x = (wv + 15u) >> 4;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, SVR_WAVES_PER_EU) void k_pathtrace_uloop(const
     const uint32_t n_tiles = ((wv + 7u) >> 3) * ((w.n_rows + 7u) >> 3);
     const uint32_t total_items = (n_tiles * w.nframes) << 6;
 
-    Cnt c = {0, 0, 0, 0, 0, 0, 0};
+    Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // wave-uniform work range
     uint32_t it_next = 0, it_end = 0;

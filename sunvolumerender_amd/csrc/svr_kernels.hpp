@@ -7,10 +7,11 @@
 namespace svr {
 
 enum { KERNEL_AUTO = 0, KERNEL_PIXEL = 1, KERNEL_TILE = 2, KERNEL_ULOOP = 3 };
-constexpr uint32_t MASK_WORDS_MAX = 8192;   // 32 KiB of LDS: 64^3 macro-cells
+constexpr uint32_t MASK_WORDS_MAX = 8192;   // words of the LDS-resident bitmask (32 KiB): up to 64^3 macro-cells
 
 // counter slots (unsigned long long each) -- order of svr_counters in include/svr_abi.h
-enum { CNT_PATHS = 0, CNT_VOL_TAPS, CNT_WOODCOCK, CNT_SCATTER, CNT_SHADOW, CNT_RAYCAST, CNT_LOOP, CNT_TAPS_EXEC, CNT_N };
+enum { CNT_PATHS = 0, CNT_VOL_TAPS, CNT_WOODCOCK, CNT_SCATTER, CNT_SHADOW, CNT_RAYCAST, CNT_LOOP, CNT_TAPS_EXEC,
+       CNT_WALKS_RAYSKIP, CNT_ITERS_RAYSKIP, CNT_ITERS_PREFIX, CNT_RESERVED, CNT_N };
 
 struct LaunchCfg {
     int kernel;            // KERNEL_*
@@ -28,7 +29,9 @@ hipError_t launch_trace_tile(const DevScene& scene, const DevWork& work, const L
 // acceleration data (svr_accel.hip): per-macro-cell min/max of the raw voxels, and the empty bitmask
 hipError_t launch_minmax(const uint16_t* src_linear, uint16_t* mm, int nx, int ny, int nz, int shift,
                          int gx, int gy, int gz, hipStream_t stream);
-hipError_t launch_empty_mask(const uint16_t* mm, uint32_t n_cells, const uint32_t* tf_zero_prefix, int tf_n,
+// mask: 2*mask_words words; [0, mask_words) = deep-empty bits (macro-cell and its 26 neighbours all empty;
+// the only mask the trace kernel reads), [mask_words, 2*mask_words) = plain empty bits (scratch)
+hipError_t launch_empty_mask(const uint16_t* mm, int gx, int gy, int gz, const uint32_t* tf_zero_prefix, int tf_n,
                              float densityScale, uint32_t* mask, uint32_t mask_words, hipStream_t stream);
 // hdr_to_ldr over the owned pixels
 hipError_t launch_tonemap(const DevScene& scene, const DevWork& work, hipStream_t stream);

@@ -25,7 +25,7 @@ namespace svr {
 
 struct LdsTile {
     float alpha[SVR_TF_MAX + SVR_TF_PAD];      // entry e = alpha of texel clamp(e-1)
-    uint32_t mask[MASK_WORDS_MAX];
+    uint32_t mask[MASK_WORDS_MAX];             // deep-empty bits: the macro-cell and its 26 neighbours are transparent
 };
 struct LdsTileNoMask {
     float alpha[SVR_TF_MAX + SVR_TF_PAD];
@@ -125,45 +125,98 @@ SVR_DEV float alpha_of(const LDS& L, const DevScene& s, float x)
     return lerpf(L.alpha[e], L.alpha[e + 1], a);
 }
 
-// macro-cell bit of a trilinear cell; only cells -1..N-2 (all 8 voxels inside the array or on its
-// first border layer) are covered by the mask, the outermost layers always fetch
+// macro-cell bit of a trilinear cell.  The mask covers the cells c = -1 .. N-1 (c+1 in [0, N]: every cell
+// a point of the texture domain maps to); cells further out (clip planes beyond the volume, gradient
+// taps) always fetch.
 template <typename LDS>
 SVR_DEV bool cell_is_empty(const LDS& L, const DevScene& s, const Cell& c)
 {
     uint32_t ux = (uint32_t)(c.cx + 1), uy = (uint32_t)(c.cy + 1), uz = (uint32_t)(c.cz + 1);
-    bool inb = (ux < (uint32_t)s.nx) & (uy < (uint32_t)s.ny) & (uz < (uint32_t)s.nz);
+    bool inb = (ux <= (uint32_t)s.nx) & (uy <= (uint32_t)s.ny) & (uz <= (uint32_t)s.nz);
     uint32_t sh = (uint32_t)s.mc_shift;
-    uint32_t m = (ux >> sh) + __umul24(uy >> sh, (uint32_t)s.mc_gx) + __umul24(uz >> sh, (uint32_t)s.mc_gxy);
+    uint32_t qx = min(ux >> sh, (uint32_t)s.mc_gx - 1u), qy = min(uy >> sh, (uint32_t)s.mc_gy - 1u),
+             qz = min(uz >> sh, (uint32_t)s.mc_gz - 1u);
+    uint32_t m = qx + __umul24(qy, (uint32_t)s.mc_gx) + __umul24(qz, (uint32_t)s.mc_gxy);
     m = inb ? m : 0u;
     uint32_t word = L.mask[m >> 5];
     return inb && ((word >> (m & 31u)) & 1u);
 }
 
+// Conservative march of the ray segment [t0, t1] through the macro grid (3D-DDA): returns the ray
+// parameter at which the segment first enters a macro-cell that is not deep-empty, or +inf if it
+// never does.  Float error in the march is far below one macro-cell, and a deep-empty cell has only
+// empty neighbours, so every point of the ray with t < result lies in an empty macro-cell.
+template <typename LDS>
+SVR_DEV float first_occupied(const DevScene& s, const LDS& L, v3 o, v3 d, float t0, float t1)
+{
+    const float INF = u2f(SVR_INF_BITS);
+    float Ax = fma_(o.x - s.vmin[0], s.mc_scale[0], s.mc_off), Bx = d.x * s.mc_scale[0];
+    float Ay = fma_(o.y - s.vmin[1], s.mc_scale[1], s.mc_off), By = d.y * s.mc_scale[1];
+    float Az = fma_(o.z - s.vmin[2], s.mc_scale[2], s.mc_off), Bz = d.z * s.mc_scale[2];
+    int gx = s.mc_gx, gy = s.mc_gy, gz = s.mc_gz;
+    int ix = min(max((int)__builtin_floorf(fma_(Bx, t0, Ax)), 0), gx - 1);
+    int iy = min(max((int)__builtin_floorf(fma_(By, t0, Ay)), 0), gy - 1);
+    int iz = min(max((int)__builtin_floorf(fma_(Bz, t0, Az)), 0), gz - 1);
+    int sx = Bx > 0.f ? 1 : -1, sy = By > 0.f ? 1 : -1, sz = Bz > 0.f ? 1 : -1;
+    float rx = __builtin_amdgcn_rcpf(Bx), ry = __builtin_amdgcn_rcpf(By), rz = __builtin_amdgcn_rcpf(Bz);
+    float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
+    float tnx = (Bx != 0.f) ? ((float)(ix + (Bx > 0.f ? 1 : 0)) - Ax) * rx : INF;
+    float tny = (By != 0.f) ? ((float)(iy + (By > 0.f ? 1 : 0)) - Ay) * ry : INF;
+    float tnz = (Bz != 0.f) ? ((float)(iz + (Bz > 0.f ? 1 : 0)) - Az) * rz : INF;
+    dtx = (Bx != 0.f) ? dtx : INF; dty = (By != 0.f) ? dty : INF; dtz = (Bz != 0.f) ? dtz : INF;
+    float t = t0;
+    const uint32_t* deep = L.mask;
+    int guard = gx + gy + gz + 4;
+    for (int it = 0; it < guard; ++it) {
+        uint32_t q = (uint32_t)ix + __umul24((uint32_t)iy, (uint32_t)gx) + __umul24((uint32_t)iz, (uint32_t)s.mc_gxy);
+        if (!((deep[q >> 5] >> (q & 31u)) & 1u)) return t;
+        float tn = fmin_(tnx, fmin_(tny, tnz));
+        if (!(tn <= t1)) return INF;          // the segment ends inside this cell
+        t = tn;
+        if (tnx <= tny && tnx <= tnz) { ix += sx; tnx += dtx; if ((uint32_t)ix >= (uint32_t)gx) return INF; }
+        else if (tny <= tnz) { iy += sy; tny += dty; if ((uint32_t)iy >= (uint32_t)gy) return INF; }
+        else { iz += sz; tnz += dtz; if ((uint32_t)iz >= (uint32_t)gz) return INF; }
+    }
+    return t;   // guard exhausted (cannot happen: each step leaves a cell): treat the rest as occupied
+}
+
 // sample_distance, woodcock_tracking.h:20-51.  `val` returns the intensity fetched by the accepted
 // iteration (= volume(PointOnRay(t)), the scatter point's intensity, pathtracer.cu:241).
+// rng_live: a random draw of this path can follow the walk; if not, and the walk provably cannot
+// collide, its result (-FLT_MAX) is known without running it.
 template <int LAYOUT, bool COUNT, bool SKIP, typename LDS>
 SVR_DEV float walk(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float& tMin, float& tMax,
-                   float& val, Cnt& c)
+                   float& val, bool rng_live, Cnt& c)
 {
     float tNear, tFar;
     if (!volume_intersect(s, orig, dir, tNear, tFar)) return -SVR_FLT_MAX;
     tMin = tNear < 0.f ? (float)1e-6 : tNear;
     tMax = tFar;
     float t = tMin;
+    float t_occ = tMin;                 // fetches may be needed from here on
+    if (SKIP && s.ray_skip) {
+        t_occ = first_occupied(s, L, orig, dir, tMin, tMax);
+        // COUNT builds run every walk so that the iteration/tap counters stay the reference's
+        if (!COUNT && !rng_live && t_occ == u2f(SVR_INF_BITS)) return -SVR_FLT_MAX;
+    }
+    const bool ray_skippable = SKIP && s.ray_skip && !rng_live && t_occ == u2f(SVR_INF_BITS);
+    if (COUNT && ray_skippable) c.wskip++;
     for (uint32_t guard = 0;; ++guard) {
-        if (COUNT) c.iters++;
+        if (COUNT) { c.iters++; if (ray_skippable) c.iskip++; else if (SKIP && t < t_occ) c.ipre++; }
         t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
         if (t > tMax || guard >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
-        v3 p = orig + dir * t;
-        Cell cell = cell_of(s, p);
         if (COUNT) c.taps++;
         float sigma_t = 0.f;
-        bool fetch = true;
-        if (SKIP) fetch = !cell_is_empty(L, s, cell);
-        if (fetch) {
-            if (COUNT) c.exec++;
-            val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
-            sigma_t = alpha_of(L, s, val);
+        if (!SKIP || t >= t_occ) {
+            v3 p = orig + dir * t;
+            Cell cell = cell_of(s, p);
+            bool fetch = true;
+            if (SKIP) fetch = !cell_is_empty(L, s, cell);
+            if (fetch) {
+                if (COUNT) c.exec++;
+                val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
+                sigma_t = alpha_of(L, s, val);
+            }
         }
         // the accept draw is consumed either way; with sigma_t == 0 it cannot accept (xi > 0)
         if (rng_uniform(rng) < sigma_t * s.invSigmaMax) break;
@@ -187,7 +240,7 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
     int ls_id = nearest_light(s, orig, dir, ls_t);
     for (uint32_t k = 0; k < traceDepth; ++k) {
         float tMin = (float)1e-6, tMax = SVR_FLT_MAX, val = 0.f;
-        float t = walk<LAYOUT, COUNT, SKIP>(s, L_, orig, dir, rng, tMin, tMax, val, c);
+        float t = walk<LAYOUT, COUNT, SKIP>(s, L_, orig, dir, rng, tMin, tMax, val, false, c);
         if (k == 0 && ls_id >= 0) {
             t = t < 0.f ? SVR_FLT_MAX : t;
             if (ls_t < t) {
@@ -230,7 +283,8 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
             if (sample_light(s.lights[lightId], vs.pt, rng, wiL, pdfL, Li)) {
                 float sMin = (float)1e-6, sMax = SVR_FLT_MAX, sval = 0.f;
                 if (COUNT) c.shadow++;
-                float ts = walk<LAYOUT, COUNT, SKIP>(s, L_, vs.pt, wiL, rng, sMin, sMax, sval, c);
+                // the draws of sample_bsdf / roulette follow the shadow walk unless this is the last bounce
+                float ts = walk<LAYOUT, COUNT, SKIP>(s, L_, vs.pt, wiL, rng, sMin, sMax, sval, k + 1u < traceDepth, c);
                 float Tr = ((ts > sMin) && (ts < sMax)) ? 0.f : 1.f;          // transmittance.h:15-16
                 float kf = Tr * (float)s.num_lights;
                 Ld = ((bsdf_eval(vs, wiL) * kf) * Li) / pdfL;
@@ -257,9 +311,12 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
 #ifndef SVR_TILE_WAVES_PER_EU
 #define SVR_TILE_WAVES_PER_EU 4
 #endif
+#ifndef SVR_TILE_THREADS
+#define SVR_TILE_THREADS 256
+#endif
 
 template <int LAYOUT, bool COUNT, bool SKIP>
-__global__ __launch_bounds__(256, SVR_TILE_WAVES_PER_EU) void k_trace_tile(const DevScene s, const DevWork w)
+__global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_trace_tile(const DevScene s, const DevWork w)
 {
     using LDS = typename std::conditional<SKIP, LdsTile, LdsTileNoMask>::type;
     __shared__ LDS lds;
@@ -269,7 +326,7 @@ __global__ __launch_bounds__(256, SVR_TILE_WAVES_PER_EU) void k_trace_tile(const
     const uint32_t wv = w.x1 - w.x0;
     const uint32_t tiles_x = (wv + 7u) >> 3;
     const uint32_t n_tasks = tiles_x * ((w.n_rows + 7u) >> 3) * w.nframes;
-    Cnt c = {0, 0, 0, 0, 0, 0, 0};
+    Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (;;) {
         uint32_t task = 0;
@@ -298,16 +355,17 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
     uint32_t wv = w.x1 - w.x0;
     if (wv == 0 || w.n_rows == 0) return hipSuccess;
     uint32_t n_tasks = ((wv + 7u) >> 3) * ((w.n_rows + 7u) >> 3) * w.nframes;
-    uint32_t max_blocks = (uint32_t)(cfg.num_cus * cfg.blocks_per_cu);
-    uint32_t need = (n_tasks + 3u) / 4u;
+    constexpr uint32_t WPB = SVR_TILE_THREADS / 64;                       // waves per block
+    uint32_t max_blocks = (uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / WPB;
+    uint32_t need = (n_tasks + WPB - 1u) / WPB;
     uint32_t blocks = need < max_blocks ? need : max_blocks;
     if (blocks == 0) blocks = 1;
     hipError_t e = hipMemsetAsync(w.ticket, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     if (s.empty_mask != nullptr)
-        hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, true>), dim3(blocks), dim3(256), 0, st, s, w);
+        hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, true>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w);
     else
-        hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, false>), dim3(blocks), dim3(256), 0, st, s, w);
+        hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, false>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w);
     return hipGetLastError();
 }
 

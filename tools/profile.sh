@@ -15,6 +15,7 @@ i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
+  if [ -n "${PMC_ONLY:-}" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then continue; fi
   echo "== pmc $i: $group"
   timeout -k 10 240 rocprofv3 --pmc $group --output-format csv -d $OUT/pmc_$i -- $BENCH > $OUT/pmc_$i.log 2>&1 || { echo "pmc $i failed"; tail -3 $OUT/pmc_$i.log; }
 done <<'GROUPS'
