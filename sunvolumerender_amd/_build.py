@@ -1,4 +1,4 @@
-"""Build recipe for libsvr_hip.so (hipcc, gfx950 only) and for the CPU oracle.
+"""Build recipe for libsvr_hip.so (hipcc, gfx950 only).
 
 The numeric contract is part of the flags: no floating-point
 contraction, no fast-math, correctly rounded divide/sqrt.
@@ -16,8 +16,6 @@ REPO_ROOT = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
 LIB_PATH = Path(os.environ["SVR_HIP_LIB"]) if os.environ.get("SVR_HIP_LIB") else LIB_DIR / "libsvr_hip.so"
-ORACLE_DIR = REPO_ROOT / "oracle"
-ORACLE_LIB = ORACLE_DIR / "libsvr_oracle.so"
 
 HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_accel.hip"]
 HIP_HEADERS = ["svr_math.hpp", "svr_scene.hpp", "svr_device.hpp", "svr_kernels.hpp", "svr_kernel_common.hpp"]
@@ -65,17 +63,5 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
     return LIB_PATH
 
 
-def build_oracle(force: bool = False) -> Path:
-    """Compile oracle/libsvr_oracle.so (test infrastructure; never loaded by the product)."""
-    deps = [ORACLE_DIR / "svr_oracle.c", ORACLE_DIR / "svr_oracle.h", ORACLE_DIR / "Makefile"]
-    if not force and not _stale(ORACLE_LIB, deps):
-        return ORACLE_LIB
-    res = subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "libsvr_oracle.so"], capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"oracle build failed:\n{res.stdout}\n{res.stderr}")
-    return ORACLE_LIB
-
-
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose=True))
-    print(build_oracle(force="--force" in sys.argv))
