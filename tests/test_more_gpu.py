@@ -1,0 +1,216 @@
+"""More GPU parity through the C ABI: golden fixtures (no oracle involved), ray caster, row-strip sharding,
+scene edits through the Canvas protocol, error behaviour, and size-independent properties at the full
+benchmark size (c3: 512^3 volume, 1024^2 image)."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import binding
+from sunvolumerender_amd import abi, dist, host, scenes
+from tests.util import assert_bit_exact, hip_frames, oracle_frames
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.mark.parametrize("name,depth,frames", [("tiny", 1, 3), ("tiny_head", 4, 2), ("tiny_bone", 6, 1)])
+def test_golden_fixtures_bit_exact(hip_dev, name, depth, frames):
+    g = np.load(GOLD / f"render_{name}_d{depth}_f{frames}.npz")
+    sc = scenes.make_scene(name, trace_depth=depth)
+    hdr, img, c = hip_frames(hip_dev, sc, frames)
+    assert_bit_exact(hdr, g["hdr"], f"{name} vs golden")
+    assert np.array_equal(img, g["img"])
+    gold = dict(zip(g["counter_names"].tolist(), g["counters"].tolist()))
+    assert c["vol_taps"] == gold["vol_taps"] and c["woodcock_iters"] == gold["woodcock_iters"]
+
+
+@pytest.mark.parametrize("layout", [abi.LAYOUT_LINEAR, abi.LAYOUT_BRICK], ids=["linear", "brick"])
+def test_raycasting_bit_exact(hip_dev, layout):
+    """render_raycasting (raycasting.cu:15-75) against the oracle and the golden image; RGBA8 bit-exact."""
+    sc = scenes.make_scene("tiny_head")
+    ref, rc = binding.OracleScene(sc).render_raycasting()
+    canvas = host.Canvas(hip_dev, sc.width, sc.height)
+    try:
+        scenes.apply_to_canvas(sc, canvas, layout)
+        canvas.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING)
+        hip_dev.set_option(abi.OPT_COUNT, 1)
+        hip_dev.reset_counters()
+        canvas.paint(sync=True)
+        img = canvas.read_img()
+        cnt = hip_dev.counters()
+    finally:
+        hip_dev.set_option(abi.OPT_COUNT, 0)
+        canvas.close()
+    assert np.array_equal(img, ref)
+    assert np.array_equal(img, np.load(GOLD / "raycast_tiny_head.npz")["img"])
+    assert cnt["raycast_steps"] == rc["raycast_steps"]
+
+
+@pytest.mark.parametrize("world,strip", [(2, 8), (3, 16), (8, 8)])
+def test_row_strip_shards_compose(hip_dev, world, strip):
+    """Every rank's strips, rendered separately into zeroed buffers and summed, equal the single-GPU frame."""
+    sc = scenes.make_scene("tiny_head", trace_depth=2)
+    full, full_img, _ = hip_frames(hip_dev, sc, 2)
+    acc = np.zeros_like(full)
+    img_acc = np.zeros_like(full_img)
+    for r in range(world):
+        part, pimg, c = hip_frames(hip_dev, sc, 2, shard=(strip, r, world))
+        rows = dist.owned_rows(sc.height, strip, r, world)
+        other = np.setdiff1d(np.arange(sc.height), rows)
+        assert not part[other].any(), "a rank wrote outside its strips"
+        assert c["paths"] == 2 * len(rows) * sc.width
+        acc += part
+        img_acc[rows] = pimg[rows]
+    assert_bit_exact(acc, full, f"{world}-rank strip sum")
+    assert np.array_equal(img_acc, full_img)
+
+
+def test_render_window(hip_dev):
+    sc = scenes.make_scene("tiny_head")
+    full, _, _ = hip_frames(hip_dev, sc, 1)
+    part, _, c = hip_frames(hip_dev, sc, 1, window=(10, 20, 50, 61))
+    assert_bit_exact(part[20:61, 10:50], full[20:61, 10:50], "window")
+    mask = np.ones(full.shape[:2], bool)
+    mask[20:61, 10:50] = False
+    assert not part[mask].any() and c["paths"] == 40 * 41
+
+
+def test_canvas_edits_restart_and_match_oracle(hip_dev):
+    """Setter -> setup_* -> frameNo = 0 (gui/canvas.h:43-175): density scale, clip planes, lights, exposure."""
+    base = scenes.make_scene("tiny_head", trace_depth=2)
+    canvas = host.Canvas(hip_dev, base.width, base.height)
+    try:
+        scenes.apply_to_canvas(base, canvas)
+        canvas.paint()
+        canvas.paint()
+        assert canvas.renderParams.frameNo == 2
+        canvas.SetDensityScale(0.7)
+        assert canvas.renderParams.frameNo == 0
+        canvas.SetClipPlane((-0.5, 1.0), (-1.0, 0.8), (-1.0, 1.0))
+        canvas.SetExposure(0.5)
+        canvas.paint()
+        canvas.paint(sync=True)
+        hdr, img = canvas.read_hdr(), canvas.read_img()
+    finally:
+        canvas.close()
+    edited = scenes.make_scene("tiny_head", trace_depth=2, density_scale=0.7, exposure=0.5,
+                               clip=((-0.5, 1.0), (-1.0, 0.8), (-1.0, 1.0)))
+    ref_hdr, ref_img, _ = oracle_frames(edited, 2)
+    assert_bit_exact(hdr, ref_hdr, "after edits")
+    assert np.array_equal(img, ref_img)
+
+
+def test_transfer_function_edit_rebuilds_skip_mask(hip_dev):
+    """A TF that makes 'air' slightly opaque must invalidate the empty-space mask (svr_update_tf_texture)."""
+    sc = scenes.make_scene("tiny_head", trace_depth=1)
+    canvas = host.Canvas(hip_dev, sc.width, sc.height)
+    try:
+        scenes.apply_to_canvas(sc, canvas)
+        canvas.paint(sync=True)
+        t2 = sc.tf_rgba.copy()
+        t2[:, 3] = np.maximum(t2[:, 3], np.float32(0.02))          # haze everywhere: nothing is skippable
+        hip_dev.check(hip_dev.lib.svr_update_tf_texture(canvas.transferFunction.tex, t2.ctypes.data_as(C.c_void_p), t2.shape[0], 0))
+        canvas.ReStartRender()
+        canvas.paint(sync=True)
+        hdr = canvas.read_hdr()
+    finally:
+        canvas.close()
+    hazy = scenes.make_scene("tiny_head", trace_depth=1)
+    hazy.tf_rgba = t2
+    ref, _, _ = oracle_frames(hazy, 1)
+    assert_bit_exact(hdr, ref, "after TF edit")
+
+
+def test_errors_are_reported_not_swallowed(hip_dev):
+    lib = hip_dev.lib
+    rp = abi.RenderParams(1, 0, None)
+    lib.render_pathtracer(None, C.byref(rp))
+    assert lib.svr_last_error_code() != 0
+    lib.svr_clear_error()
+    vol = abi.cudaVolume()
+    vol.tex = 0xDEAD
+    lib.setup_volume(C.byref(vol))
+    tf = abi.cudaTransferFunction()
+    tf.tex, tf.maxOpacity = 0xBEEF, 0.5
+    cam = host.camera_setup((0, 0, 5), (0, 0, 0), (0, 1, 0), imageW=16, imageH=16)
+    img = hip_dev.malloc(16 * 16 * 4)
+    lib.render_raycasting(C.c_void_p(img), C.byref(vol), C.byref(tf), C.byref(cam), C.c_float(1.0))
+    assert lib.svr_last_error_code() != 0 and b"handle" in lib.svr_last_error()
+    lib.svr_clear_error()
+    hip_dev.free(img)
+    assert lib.svr_create_tf_texture(None, 16, 0) == 0 and lib.svr_last_error_code() != 0
+    lib.svr_clear_error()
+
+
+# ---------------- full benchmark size ----------------
+@pytest.fixture(scope="module")
+def c3_canvas(hip_dev):
+    sc = scenes.make_scene("c3")
+    canvas = host.Canvas(hip_dev, sc.width, sc.height)
+    scenes.apply_to_canvas(sc, canvas)
+    yield sc, canvas
+    canvas.close()
+
+
+def test_c3_window_matches_oracle(hip_dev, c3_canvas):
+    """Bit-exact against the oracle at the benchmark's full sizes on windows the oracle finishes in seconds."""
+    sc, canvas = c3_canvas
+    canvas.ReStartRender()
+    canvas.paint()
+    canvas.paint(sync=True)
+    hdr = canvas.read_hdr()
+    o = binding.OracleScene(sc)
+    ref = o.new_hdr()
+    wins = [(480, 500, 544, 532), (96, 600, 160, 616), (900, 40, 964, 56)]
+    for f in range(2):
+        for w in wins:
+            o.render_pathtracer(ref, f, window=w)
+    for (x0, y0, x1, y1) in wins:
+        assert_bit_exact(hdr[y0:y1, x0:x1], ref[y0:y1, x0:x1], f"c3 window {(x0, y0, x1, y1)}")
+
+
+def test_c3_properties(hip_dev, c3_canvas):
+    """Size-independent properties at 512^3 / 1024^2: determinism, batch == sequential, kernels agree,
+    skipping changes nothing, running mean stays inside the per-frame extremes."""
+    sc, canvas = c3_canvas
+
+    def run(frames, batch=False, kernel=abi.KERNEL_AUTO, skip=1, rayskip=1):
+        hip_dev.set_option(abi.OPT_KERNEL, kernel)
+        hip_dev.set_option(abi.OPT_EMPTY_SKIP, skip)
+        hip_dev.set_option(abi.OPT_RAY_SKIP, rayskip)
+        canvas.ReStartRender()
+        if batch:
+            canvas.paint_frames(frames)
+        else:
+            for _ in range(frames):
+                canvas.paint()
+        hip_dev.synchronize()
+        out = canvas.read_hdr(), canvas.read_img()
+        hip_dev.set_option(abi.OPT_KERNEL, abi.KERNEL_AUTO)
+        hip_dev.set_option(abi.OPT_EMPTY_SKIP, 1)
+        hip_dev.set_option(abi.OPT_RAY_SKIP, 1)
+        return out
+
+    a, ai = run(3)
+    b, bi = run(3)
+    assert_bit_exact(a, b, "determinism")
+    c, ci = run(3, batch=True)
+    assert_bit_exact(a, c, "batch == sequential")
+    d, _ = run(3, skip=0)
+    assert_bit_exact(a, d, "empty-space skipping off")
+    e, _ = run(3, rayskip=0)
+    assert_bit_exact(a, e, "whole-ray skipping off")
+    f, _ = run(3, kernel=abi.KERNEL_PIXEL)
+    assert_bit_exact(a, f, "baseline kernel")
+    assert np.array_equal(ai, bi) and np.array_equal(ai, ci)
+    assert np.isfinite(a).all() and (a >= 0).all()
+    one, one_img = run(1)
+    assert (a.max(axis=(0, 1)) <= 3 * np.maximum(one.max(axis=(0, 1)), 1e-6) * 1e6).all()
+    # tone map of the accumulated buffer (hdr_to_ldr alone) reproduces img
+    img2 = hip_dev.malloc(sc.width * sc.height * 4)
+    hip_dev.check(hip_dev.lib.svr_hdr_to_ldr(C.c_void_p(img2), C.byref(canvas.renderParams)))
+    got = hip_dev.to_host(img2, (sc.height, sc.width, 4), np.uint8)
+    hip_dev.free(img2)
+    assert np.array_equal(got, one_img)
