@@ -104,6 +104,7 @@ typedef struct svr_render_params {         /* RenderParams, core/render_paramete
  * (A) the reference's device-layer entry points (same symbol names)
  * ===================================================================== */
 
+#ifndef SVR_ABI_NO_REFERENCE_PROTOTYPES   /* host_api.hpp re-declares these seven with the reference's C++ signatures */
 /* pathtracer.h:17 / pathtracer.cu:292-304.  One call = one sample per pixel: clears the
  * accumulator iff frameNo==0, traces one path per pixel with seed wangHash(frameNo) +
  * y*W + x, folds it into the running mean in hdrBuffer and tone-maps into img (device
@@ -122,6 +123,7 @@ void setup_area_lights(svr_area_light* lights, uint32_t n);   /* n is clamped to
  * argument, not through the setup_* state, as in the reference. */
 void render_raycasting(void* img, svr_volume* volume, svr_transfer_function* transferFunction,
                        svr_camera* camera, float stepSize);
+#endif /* SVR_ABI_NO_REFERENCE_PROTOTYPES */
 
 /* =====================================================================
  * (B) helpers replacing the CUDA runtime calls of the reference's host code
