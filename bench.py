@@ -109,10 +109,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    # SVR_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals; the driver's runs use nccl (= RCCL)
+    backend = os.environ.get("SVR_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     t_setup = time.perf_counter()
     scene = scenes.make_scene(args.scene, trace_depth=args.trace_depth)
@@ -169,13 +175,19 @@ def main():
     for _ in range(args.steps):
         step()
     if world > 1:
-        dist.reduce(hdr, dst=0, op=dist.ReduceOp.SUM)     # strips are disjoint; other ranks' rows are zero
+        # one collective per output: strips are disjoint and every rank's buffer is zero outside its own
+        if backend == "nccl":
+            dist.reduce(hdr, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            h = hdr.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            hdr.copy_(h)
     barrier()
     elapsed = time.perf_counter() - t0
     dev.set_option(abi.OPT_TIMING, 0)
     k_ms, k_n = dev.kernel_time()
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -184,7 +196,7 @@ def main():
     cnt = None
     if counters is not None:
         keys = ["paths", "vol_taps", "vol_taps_executed", "woodcock_iters", "scatter_events", "shadow_walks"]
-        tc = torch.tensor([counters[k] for k in keys], dtype=torch.float64, device="cuda")
+        tc = torch.tensor([counters[k] for k in keys], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         local = {k: counters[k] for k in keys}
         if world > 1:
             dist.all_reduce(tc, op=dist.ReduceOp.SUM)
