@@ -182,7 +182,8 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
                                      comments out, pathtracer.cu:233).  default 0 = reference behaviour */
 #define SVR_OPT_KERNEL 2          /* 0 auto (= 2); 1 one block per 16x16 tile (reference-shaped baseline);
                                      2 persistent waves, one 8x8 tile-task per wave, empty-space skipping (default);
-                                     3 persistent waves with per-lane state machine and ballot/mbcnt lane regeneration */
+                                     3 persistent waves with per-lane state machine and ballot/mbcnt lane regeneration;
+                                     4 wavefront: gen / walk / shade kernels over dense queues with ballot + prefix-sum compaction */
 #define SVR_OPT_COUNT 3           /* 1: count volume taps etc. (slower; for roofline accounting) */
 #define SVR_OPT_TIMING 4          /* 1: bracket the path-tracing kernel with HIP events */
 #define SVR_OPT_SKIP_TONEMAP 5    /* 1: render_pathtracer does not run hdr_to_ldr (batch rendering) */

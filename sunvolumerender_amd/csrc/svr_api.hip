@@ -86,10 +86,13 @@ struct Context {
         hipStream_t stream = nullptr;
         hipEvent_t traced = nullptr, resolved = nullptr;
         bool used = false;
+        float4* planes[svr::WF_QUEUE_PLANES] = {};   // wavefront queues (allocated on first use)
+        uint32_t* wf_counts = nullptr;
     } sets[NSETS];
+    size_t queue_capacity = 0;
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 64, opt_empty_skip = 1, opt_ray_skip = 1;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     bool mask_valid = false;
@@ -155,8 +158,8 @@ int ensure_init()
     g.info = buf;
     HIP_TRY(hipMalloc((void**)&g.d_counters, sizeof(svr_counters)));
     HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
-    HIP_TRY(hipMalloc((void**)&g.d_ticket, 64 * Context::NSETS));
-    HIP_TRY(hipMemset(g.d_ticket, 0, 64 * Context::NSETS));
+    HIP_TRY(hipMalloc((void**)&g.d_ticket, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * Context::NSETS));
+    HIP_TRY(hipMemset(g.d_ticket, 0, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * Context::NSETS));
     HIP_TRY(hipMalloc((void**)&g.d_mask, 2 * svr::MASK_WORDS_MAX * sizeof(uint32_t)));
     for (int i = 0; i < Context::NSETS; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&g.sets[i].stream, hipStreamNonBlocking));
@@ -291,6 +294,7 @@ int fill_work(svr::DevWork& w, uint32_t W, uint32_t H)
     w.counters = g.d_counters;
     w.ticket = g.d_ticket;
     w.refill_min_idle = (uint32_t)g.opt_refill;
+    w.debug_stop = (uint32_t)g.opt_debug_stop;
     w.strip_rows = g.strip_rows ? g.strip_rows : 1;
     w.rank = g.rank;
     w.world = g.world;
@@ -392,6 +396,22 @@ int ensure_slots(uint32_t W, uint32_t H)
     return 0;
 }
 
+int ensure_queues(uint32_t W, uint32_t H)
+{
+    size_t need = (size_t)W * H * Context::GROUP;
+    if (g.queue_capacity == need) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& st : g.sets) {
+        for (auto& p : st.planes) if (p) { HIP_TRY(hipFree(p)); p = nullptr; }
+        if (!st.wf_counts) HIP_TRY(hipMalloc((void**)&st.wf_counts, 64 * sizeof(uint32_t)));
+    }
+    if (need >= ((size_t)1 << 31)) return fail(-3, "frame too large for the wavefront queues");
+    for (auto& st : g.sets)
+        for (auto& p : st.planes) HIP_TRY(hipMalloc((void**)&p, need * sizeof(float4)));
+    g.queue_capacity = need;
+    return 0;
+}
+
 int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool tonemap)
 {
     if (ensure_init()) return g.err_code;
@@ -407,7 +427,11 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     if (ensure_slots(s.imageW, s.imageH)) return g.err_code;
     svr::LaunchCfg cfg;
     cfg.kernel = g.opt_kernel == svr::KERNEL_AUTO ? svr::KERNEL_TILE : g.opt_kernel;
-    if (cfg.kernel == svr::KERNEL_TILE && ensure_mask(s)) return g.err_code;
+    if ((cfg.kernel == svr::KERNEL_TILE || cfg.kernel == svr::KERNEL_WAVEFRONT) && ensure_mask(s)) return g.err_code;
+    if (cfg.kernel == svr::KERNEL_WAVEFRONT) {
+        if (rp->traceDepth > 15) return fail(-3, "the wavefront kernels support traceDepth <= 15 (got %u)", rp->traceDepth);
+        if (ensure_queues(s.imageW, s.imageH)) return g.err_code;
+    }
     cfg.count = g.opt_count != 0;
     cfg.num_cus = g.num_cus;
     cfg.blocks_per_cu = g.opt_blocks_per_cu > 0 ? g.opt_blocks_per_cu : 4;
@@ -424,7 +448,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         w.img = (tonemap && last && !g.opt_skip_tonemap) ? (uint8_t*)img : nullptr;
         w.lbuf = set.lbuf;
         w.slot_stride = (uint32_t)g.slot_floats;
-        w.ticket = g.d_ticket + 16 * si;
+        w.ticket = g.d_ticket + (size_t)svr::TICKET_SHARDS * svr::TICKET_STRIDE * si;
         w.traceDepth = rp->traceDepth;
         w.frame0 = rp->frameNo + g0;
         w.nframes = n;
@@ -436,7 +460,9 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
             slot = g.ev_head;
             HIP_TRY(hipEventRecord(g.ev0[slot], ts));
         }
-        if (cfg.kernel == svr::KERNEL_TILE) HIP_TRY(svr::launch_trace_tile(s, w, cfg, ts));
+        if (cfg.kernel == svr::KERNEL_WAVEFRONT)
+            HIP_TRY(svr::launch_wavefront(s, w, cfg, set.planes, set.wf_counts, (uint32_t)g.queue_capacity, ts));
+        else if (cfg.kernel == svr::KERNEL_TILE) HIP_TRY(svr::launch_trace_tile(s, w, cfg, ts));
         else HIP_TRY(svr::launch_pathtrace(s, w, cfg, ts));
         if (g.opt_timing) {
             HIP_TRY(hipEventRecord(g.ev1[slot], ts));
@@ -484,6 +510,8 @@ void svr_shutdown(void)
     g.textures.clear();
     for (auto& st : g.sets) {
         if (st.lbuf) hipFree(st.lbuf);
+        for (auto& p : st.planes) if (p) hipFree(p);
+        if (st.wf_counts) hipFree(st.wf_counts);
         if (st.stream) hipStreamDestroy(st.stream);
         if (st.traced) hipEventDestroy(st.traced);
         if (st.resolved) hipEventDestroy(st.resolved);
@@ -795,7 +823,7 @@ int svr_set_option(int key, int value)
     switch (key) {
     case SVR_OPT_ENV_ON_ESCAPE: g.opt_env_on_escape = value ? 1 : 0; return 0;
     case SVR_OPT_KERNEL:
-        if (value < 0 || value > 3) return fail(-6, "SVR_OPT_KERNEL: bad value %d", value);
+        if (value < 0 || value > 4) return fail(-6, "SVR_OPT_KERNEL: bad value %d", value);
         g.opt_kernel = value; return 0;
     case SVR_OPT_COUNT: g.opt_count = value ? 1 : 0; return 0;
     case SVR_OPT_TIMING: g.opt_timing = value ? 1 : 0; return 0;
@@ -806,6 +834,7 @@ int svr_set_option(int key, int value)
     case SVR_OPT_PIPELINE: g.opt_pipeline = value ? 1 : 0; return 0;
     case SVR_OPT_EMPTY_SKIP: g.opt_empty_skip = value ? 1 : 0; return 0;
     case SVR_OPT_RAY_SKIP: g.opt_ray_skip = value ? 1 : 0; return 0;
+    case 100: g.opt_debug_stop = value; return 0;      // undocumented timing ablation (wrong images)
     case SVR_OPT_REFILL_MIN_IDLE:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_REFILL_MIN_IDLE: bad value %d (1..64)", value);
         g.opt_refill = value; return 0;

@@ -6,7 +6,10 @@
 
 namespace svr {
 
-enum { KERNEL_AUTO = 0, KERNEL_PIXEL = 1, KERNEL_TILE = 2, KERNEL_ULOOP = 3 };
+enum { KERNEL_AUTO = 0, KERNEL_PIXEL = 1, KERNEL_TILE = 2, KERNEL_ULOOP = 3, KERNEL_WAVEFRONT = 4 };
+constexpr int WF_QUEUE_PLANES = 18;         // 2 ray queues + 1 hit queue, 6 float4 planes each
+constexpr uint32_t TICKET_SHARDS = 8;       // sharded work counters (one per XCD group), 128 B apart
+constexpr uint32_t TICKET_STRIDE = 32;      // in uint32 words
 constexpr uint32_t MASK_WORDS_MAX = 8192;   // words of the LDS-resident bitmask (32 KiB): up to 64^3 macro-cells
 
 // counter slots (unsigned long long each) -- order of svr_counters in include/svr_abi.h
@@ -26,6 +29,10 @@ hipError_t launch_pathtrace(const DevScene& scene, const DevWork& work, const La
 hipError_t launch_resolve(const DevScene& scene, const DevWork& work, hipStream_t stream);
 // default trace kernel (svr_trace_tile.hip): persistent waves, one 8x8 tile-task per wave, empty-space skipping
 hipError_t launch_trace_tile(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
+// wavefront kernels (svr_wavefront.hip): gen -> [walk -> shade] x depth over dense queues with ballot/prefix-sum
+// compaction; planes = WF_QUEUE_PLANES device arrays of `capacity` float4, counts = 32 words
+hipError_t launch_wavefront(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, float4* const* planes,
+                            uint32_t* counts, uint32_t capacity, hipStream_t stream);
 // acceleration data (svr_accel.hip): per-macro-cell min/max of the raw voxels, and the empty bitmask
 hipError_t launch_minmax(const uint16_t* src_linear, uint16_t* mm, int nx, int ny, int nz, int shift,
                          int gx, int gy, int gz, hipStream_t stream);

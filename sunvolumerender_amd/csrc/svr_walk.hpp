@@ -1,0 +1,245 @@
+// svr_walk.hpp -- the Woodcock-walk machinery shared by the tile kernel (svr_trace_tile.hip) and the
+// wavefront kernels (svr_wavefront.hip): LDS-resident alpha LUT + deep-empty bitmask, the software
+// tex3D (cell + fetch), the conservative whole-ray march, and the walk loop itself.
+#pragma once
+#include "svr_kernel_common.hpp"
+
+namespace svr {
+
+struct LdsTile {
+    float alpha[SVR_TF_MAX + SVR_TF_PAD];      // entry e = alpha of texel clamp(e-1)
+    uint32_t mask[MASK_WORDS_MAX];             // deep-empty bits: the macro-cell and its 26 neighbours are transparent
+};
+struct LdsTileNoMask {
+    float alpha[SVR_TF_MAX + SVR_TF_PAD];
+    uint32_t mask[1];
+};
+
+template <typename LDS>
+SVR_DEV void lds_tile_load(LDS& L, const DevScene& s, bool with_mask)
+{
+    const int n = s.tf_n;
+    for (int e = threadIdx.x; e < n + SVR_TF_PAD; e += blockDim.x) {
+        int t = min(max(e - 1, 0), n - 1);
+        L.alpha[e] = s.tf[4 * t + 3];
+    }
+    if (with_mask) {
+        const uint4* src = reinterpret_cast<const uint4*>(s.empty_mask);
+        uint4* dst = reinterpret_cast<uint4*>(L.mask);
+        for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += blockDim.x) dst[q] = src[q];
+    }
+    __syncthreads();
+}
+
+// trilinear cell of a world-space point: cuda_volume.h:87-90 + the first half of tex3D
+struct Cell { int cx, cy, cz; float a, b, g; };
+
+SVR_DEV Cell cell_of(const DevScene& s, v3 p)
+{
+    float u = (p.x - s.vmin[0]) * s.invSize[0];
+    float v = (p.y - s.vmin[1]) * s.invSize[1];
+    float w = (p.z - s.vmin[2]) * s.invSize[2];
+    float xb = fma_(u, s.fnx, -0.5f);
+    float yb = fma_(v, s.fny, -0.5f);
+    float zb = fma_(w, s.fnz, -0.5f);
+    float fx = __builtin_floorf(xb), fy = __builtin_floorf(yb), fz = __builtin_floorf(zb);
+    Cell c;
+    c.a = xb - fx; c.b = yb - fy; c.g = zb - fz;
+    fx = fmin_(fmax_(fx, -2.f), s.fnx);
+    fy = fmin_(fmax_(fy, -2.f), s.fny);
+    fz = fmin_(fmax_(fz, -2.f), s.fnz);
+    c.cx = (int)fx; c.cy = (int)fy; c.cz = (int)fz;
+    return c;
+}
+
+SVR_DEV float ld_u16(const uint16_t* base, uint32_t byte_off)
+{
+    return (float)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// second half of tex3D<float>: 8 voxels + float-weight trilinear filter, normalised by 1/65535
+template <int LAYOUT>
+SVR_DEV float tex_fetch(const DevScene& s, const Cell& c)
+{
+    uint32_t i = (uint32_t)(c.cx + VOL_PAD), j = (uint32_t)(c.cy + VOL_PAD), k = (uint32_t)(c.cz + VOL_PAD);
+    const uint16_t* vox = s.vox;
+    float v000, v100, v010, v110, v001, v101, v011, v111;
+    if (LAYOUT == LAYOUT_LINEAR) {
+        uint32_t base = ((k * (uint32_t)s.sz + j * (uint32_t)s.sy) + i) << 1;
+        uint32_t dy = (uint32_t)s.sy << 1, dz = (uint32_t)s.sz << 1;
+        v000 = ld_u16(vox, base);           v100 = ld_u16(vox, base + 2u);
+        v010 = ld_u16(vox, base + dy);      v110 = ld_u16(vox, base + dy + 2u);
+        v001 = ld_u16(vox, base + dz);      v101 = ld_u16(vox, base + dz + 2u);
+        v011 = ld_u16(vox, base + dz + dy); v111 = ld_u16(vox, base + dz + dy + 2u);
+    } else {
+        // brick = 8x4x4 voxels = 256 B; byte offsets
+        uint32_t i1 = i + 1u, j1 = j + 1u, k1 = k + 1u;
+        uint32_t X0 = ((i >> 3) << 8) + ((i & 7u) << 1), X1 = ((i1 >> 3) << 8) + ((i1 & 7u) << 1);
+        uint32_t ys = (uint32_t)s.bnx << 8;
+        uint32_t zs = (uint32_t)(s.bny * s.bnx) << 8;                     // < 2^24, checked on the host
+        uint32_t Y0 = __umul24(j >> 2, ys) + ((j & 3u) << 4), Y1 = __umul24(j1 >> 2, ys) + ((j1 & 3u) << 4);
+        uint32_t Z0 = __umul24(k >> 2, zs) + ((k & 3u) << 6), Z1 = __umul24(k1 >> 2, zs) + ((k1 & 3u) << 6);
+        uint32_t a00 = Y0 + Z0, a10 = Y1 + Z0, a01 = Y0 + Z1, a11 = Y1 + Z1;
+        v000 = ld_u16(vox, a00 + X0); v100 = ld_u16(vox, a00 + X1);
+        v010 = ld_u16(vox, a10 + X0); v110 = ld_u16(vox, a10 + X1);
+        v001 = ld_u16(vox, a01 + X0); v101 = ld_u16(vox, a01 + X1);
+        v011 = ld_u16(vox, a11 + X0); v111 = ld_u16(vox, a11 + X1);
+    }
+    float c00 = lerpf(v000, v100, c.a);
+    float c10 = lerpf(v010, v110, c.a);
+    float c01 = lerpf(v001, v101, c.a);
+    float c11 = lerpf(v011, v111, c.a);
+    float c0 = lerpf(c00, c10, c.b);
+    float c1 = lerpf(c01, c11, c.b);
+    return lerpf(c0, c1, c.g) * 1.5259021896696422e-05f;
+}
+
+template <int LAYOUT>
+SVR_DEV float intensity_at(const DevScene& s, v3 p)
+{
+    return tex_fetch<LAYOUT>(s, cell_of(s, p)) * s.densityScale;
+}
+
+template <typename LDS>
+SVR_DEV float alpha_of(const LDS& L, const DevScene& s, float x)
+{
+    int e; float a;
+    lds_tf_coord(s, x, e, a);
+    return lerpf(L.alpha[e], L.alpha[e + 1], a);
+}
+
+// macro-cell bit of a trilinear cell.  The mask covers the cells c = -1 .. N-1 (c+1 in [0, N]: every cell
+// a point of the texture domain maps to); cells further out (clip planes beyond the volume, gradient
+// taps) always fetch.
+template <typename LDS>
+SVR_DEV bool cell_is_empty(const LDS& L, const DevScene& s, const Cell& c)
+{
+    uint32_t ux = (uint32_t)(c.cx + 1), uy = (uint32_t)(c.cy + 1), uz = (uint32_t)(c.cz + 1);
+    bool inb = (ux <= (uint32_t)s.nx) & (uy <= (uint32_t)s.ny) & (uz <= (uint32_t)s.nz);
+    uint32_t sh = (uint32_t)s.mc_shift;
+    uint32_t qx = min(ux >> sh, (uint32_t)s.mc_gx - 1u), qy = min(uy >> sh, (uint32_t)s.mc_gy - 1u),
+             qz = min(uz >> sh, (uint32_t)s.mc_gz - 1u);
+    uint32_t m = qx + __umul24(qy, (uint32_t)s.mc_gx) + __umul24(qz, (uint32_t)s.mc_gxy);
+    m = inb ? m : 0u;
+    uint32_t word = L.mask[m >> 5];
+    return inb && ((word >> (m & 31u)) & 1u);
+}
+
+// Conservative march of the ray segment [t0, t1] through the macro grid (3D-DDA): returns the ray
+// parameter at which the segment first enters a macro-cell that is not deep-empty, or +inf if it
+// never does.  Float error in the march is far below one macro-cell, and a deep-empty cell has only
+// empty neighbours, so every point of the ray with t < result lies in an empty macro-cell.
+template <typename LDS>
+SVR_DEV float first_occupied(const DevScene& s, const LDS& L, v3 o, v3 d, float t0, float t1)
+{
+    const float INF = u2f(SVR_INF_BITS);
+    float Ax = fma_(o.x - s.vmin[0], s.mc_scale[0], s.mc_off), Bx = d.x * s.mc_scale[0];
+    float Ay = fma_(o.y - s.vmin[1], s.mc_scale[1], s.mc_off), By = d.y * s.mc_scale[1];
+    float Az = fma_(o.z - s.vmin[2], s.mc_scale[2], s.mc_off), Bz = d.z * s.mc_scale[2];
+    int gx = s.mc_gx, gy = s.mc_gy, gz = s.mc_gz;
+    int ix = min(max((int)__builtin_floorf(fma_(Bx, t0, Ax)), 0), gx - 1);
+    int iy = min(max((int)__builtin_floorf(fma_(By, t0, Ay)), 0), gy - 1);
+    int iz = min(max((int)__builtin_floorf(fma_(Bz, t0, Az)), 0), gz - 1);
+    int sx = Bx > 0.f ? 1 : -1, sy = By > 0.f ? 1 : -1, sz = Bz > 0.f ? 1 : -1;
+    float rx = __builtin_amdgcn_rcpf(Bx), ry = __builtin_amdgcn_rcpf(By), rz = __builtin_amdgcn_rcpf(Bz);
+    float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
+    float tnx = (Bx != 0.f) ? ((float)(ix + (Bx > 0.f ? 1 : 0)) - Ax) * rx : INF;
+    float tny = (By != 0.f) ? ((float)(iy + (By > 0.f ? 1 : 0)) - Ay) * ry : INF;
+    float tnz = (Bz != 0.f) ? ((float)(iz + (Bz > 0.f ? 1 : 0)) - Az) * rz : INF;
+    dtx = (Bx != 0.f) ? dtx : INF; dty = (By != 0.f) ? dty : INF; dtz = (Bz != 0.f) ? dtz : INF;
+    float t = t0;
+    const uint32_t* deep = L.mask;
+    int guard = gx + gy + gz + 4;
+    for (int it = 0; it < guard; ++it) {
+        uint32_t q = (uint32_t)ix + __umul24((uint32_t)iy, (uint32_t)gx) + __umul24((uint32_t)iz, (uint32_t)s.mc_gxy);
+        if (!((deep[q >> 5] >> (q & 31u)) & 1u)) return t;
+        float tn = fmin_(tnx, fmin_(tny, tnz));
+        if (!(tn <= t1)) return INF;          // the segment ends inside this cell
+        t = tn;
+        if (tnx <= tny && tnx <= tnz) { ix += sx; tnx += dtx; if ((uint32_t)ix >= (uint32_t)gx) return INF; }
+        else if (tny <= tnz) { iy += sy; tny += dty; if ((uint32_t)iy >= (uint32_t)gy) return INF; }
+        else { iz += sz; tnz += dtz; if ((uint32_t)iz >= (uint32_t)gz) return INF; }
+    }
+    return t;   // guard exhausted (cannot happen: each step leaves a cell): treat the rest as occupied
+}
+
+// sample_distance, woodcock_tracking.h:20-51.  `val` returns the intensity fetched by the accepted
+// iteration (= volume(PointOnRay(t)), the scatter point's intensity, pathtracer.cu:241).
+// rng_live: a random draw of this path can follow the walk; if not, and the walk provably cannot
+// collide, its result (-FLT_MAX) is known without running it.
+// Walk set-up: box intersection (woodcock_tracking.h:22-27) + whole-ray test.
+//   0 = the walk cannot collide and nothing consumes random numbers after it: result is -FLT_MAX, do not run;
+//   1 = run walk_run(tMin, tMax, t_occ);  -1 = the ray misses the (clipped) box: result is -FLT_MAX.
+template <bool COUNT, bool SKIP, typename LDS>
+SVR_DEV int walk_setup(const DevScene& s, const LDS& L, v3 orig, v3 dir, bool rng_live, float& tMin, float& tMax, float& t_occ)
+{
+    float tNear, tFar;
+    if (!volume_intersect(s, orig, dir, tNear, tFar)) return -1;
+    tMin = tNear < 0.f ? (float)1e-6 : tNear;
+    tMax = tFar;
+    t_occ = tMin;                       // fetches may be needed from here on
+    if (SKIP && s.ray_skip) {
+        t_occ = first_occupied(s, L, orig, dir, tMin, tMax);
+        // COUNT builds run every walk so that the iteration/tap counters stay the reference's
+        if (!COUNT && !rng_live && t_occ == u2f(SVR_INF_BITS)) return 0;
+    }
+    return 1;
+}
+
+// REMARCH: when the walk comes out of an occupied region into clear space, march again (used for shadow
+// walks, which start inside the medium and would otherwise test every iteration of their way out)
+template <int LAYOUT, bool COUNT, bool SKIP, bool REMARCH, typename LDS>
+SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float tMin, float tMax, float t_occ,
+                       float& val, bool rng_live, Cnt& c)
+{
+    float t = tMin;
+    uint32_t clear_run = 0;
+    const bool ray_skippable = SKIP && s.ray_skip && !rng_live && t_occ == u2f(SVR_INF_BITS);
+    if (COUNT && ray_skippable) c.wskip++;
+    bool tail_counted = false;          // COUNT builds only: the walk would have ended at a re-march
+    for (uint32_t guard = 0;; ++guard) {
+        if (COUNT) { c.iters++; if (ray_skippable) c.iskip++; else if (SKIP && t < t_occ && !tail_counted) c.ipre++; }
+        t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+        if (t > tMax || guard >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
+        if (COUNT) c.taps++;
+        float sigma_t = 0.f;
+        if (!SKIP || t >= t_occ) {
+            v3 p = orig + dir * t;
+            Cell cell = cell_of(s, p);
+            bool fetch = true;
+            if (SKIP) fetch = !cell_is_empty(L, s, cell);
+            if (fetch) {
+                if (COUNT) c.exec++;
+                val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
+                sigma_t = alpha_of(L, s, val);
+                clear_run = 0;
+            } else if (SKIP && REMARCH && s.ray_skip && ++clear_run == 2u) {
+                // second consecutive iteration in clear space (cell and neighbours transparent) after an occupied
+                // stretch: march again from here.  If nothing occupied lies ahead and no draw follows the walk,
+                // its result is known now.
+                t_occ = first_occupied(s, L, orig, dir, t, tMax);
+                if (t_occ == u2f(SVR_INF_BITS) && !rng_live) {
+                    if (!COUNT) return -SVR_FLT_MAX;
+                    if (!tail_counted) { tail_counted = true; c.wskip++; }
+                }
+            }
+        }
+        if (COUNT && tail_counted) c.iskip++;
+        // the accept draw is consumed either way; with sigma_t == 0 it cannot accept (xi > 0)
+        if (rng_uniform(rng) < sigma_t * s.invSigmaMax) break;
+    }
+    return t;
+}
+
+// sample_distance in one piece (tile kernel)
+template <int LAYOUT, bool COUNT, bool SKIP, bool REMARCH, typename LDS>
+SVR_DEV float walk(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float& tMin, float& tMax,
+                   float& val, bool rng_live, Cnt& c)
+{
+    float t_occ;
+    int r = walk_setup<COUNT, SKIP>(s, L, orig, dir, rng_live, tMin, tMax, t_occ);
+    if (r <= 0) return -SVR_FLT_MAX;
+    return walk_run<LAYOUT, COUNT, SKIP, REMARCH>(s, L, orig, dir, rng, tMin, tMax, t_occ, val, rng_live, c);
+}
+
+} // namespace svr

@@ -24,6 +24,8 @@ KERNELS = [
     (abi.KERNEL_TILE, True, "tile"),
     (abi.KERNEL_TILE, False, "tile_noskip"),
     (abi.KERNEL_ULOOP, True, "uloop"),
+    (abi.KERNEL_WAVEFRONT, True, "wavefront"),
+    (abi.KERNEL_WAVEFRONT, False, "wavefront_noskip"),
 ]
 
 
@@ -43,7 +45,7 @@ def test_pathtracer_bit_exact(hip_dev, name, depth, frames, kernel, skip, kid, l
     # algorithmic taps = what the reference issues; executed taps are fewer (reused scatter tap, skipping)
     assert c["vol_taps"] == ref_c["vol_taps"]
     assert c["vol_taps_executed"] <= c["vol_taps"]
-    if kernel == abi.KERNEL_TILE and skip:
+    if kernel in (abi.KERNEL_TILE, abi.KERNEL_WAVEFRONT) and skip:
         assert c["vol_taps_executed"] < c["vol_taps"] - ref_c["scatter_events"]
 
 

@@ -15,12 +15,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="c3")
 ap.add_argument("--frames", type=int, default=16)
 ap.add_argument("--depth", type=int, default=1)
+ap.add_argument("--stop", type=int, default=0, help="timing ablation: 1 set-up only, 2 +whole-ray test, 3 +primary walk")
 ap.add_argument("combos", nargs="+")
 a = ap.parse_args()
 
 sc = scenes.make_scene(a.scene, trace_depth=a.depth)
 dev = host.Device(0)
-print("lib:", abi.library_path().name, "|", dev.info(), flush=True)
+dev.set_option(100, a.stop)
+print("stop:", a.stop, "lib:", abi.library_path().name, "|", dev.info(), flush=True)
 canv = {}
 for combo in a.combos:
     k, lay, bpc, refill, spp, pipe, skip = [int(v) for v in combo.split(",")]
