@@ -23,10 +23,14 @@
 
 namespace svr {
 
-// re-marching shadow walks (svr_walk.hpp, REMARCH) measured slower than testing every iteration on c3
-// (0.379 vs 0.309 ms/frame: a march costs more than the ~15 iterations it saves); kept switchable
+// wave-synchronous re-marching of walks that leave an occupied stretch (svr_walk.hpp, REMARCH).  Measured on c3
+// (ms per frame): none 0.323, shadow walks only 0.292, primary only 0.400, both 0.376 -- shadow walks start inside
+// the medium and almost always end at the march; a primary march is paid by every tile that has one grazing ray.
 #ifndef SVR_SHADOW_REMARCH
-#define SVR_SHADOW_REMARCH false
+#define SVR_SHADOW_REMARCH true
+#endif
+#ifndef SVR_PRIMARY_REMARCH
+#define SVR_PRIMARY_REMARCH false
 #endif
 
 // one path: kernel_pathtracer body, pathtracer.cu:205-277
@@ -55,7 +59,7 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
     }
     for (uint32_t k = 0; k < traceDepth; ++k) {
         float tMin = (float)1e-6, tMax = SVR_FLT_MAX, val = 0.f;
-        float t = walk<LAYOUT, COUNT, SKIP, false>(s, L_, orig, dir, rng, tMin, tMax, val, false, c);
+        float t = walk<LAYOUT, COUNT, SKIP, SVR_PRIMARY_REMARCH>(s, L_, orig, dir, rng, tMin, tMax, val, false, c);
         if (debug_stop == 3u) return V3(t, val, 0.f);
         if (k == 0 && ls_id >= 0) {
             t = t < 0.f ? SVR_FLT_MAX : t;
@@ -100,7 +104,7 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
                 float sMin = (float)1e-6, sMax = SVR_FLT_MAX, sval = 0.f;
                 if (COUNT) c.shadow++;
                 // the draws of sample_bsdf / roulette follow the shadow walk unless this is the last bounce
-                float ts = walk<LAYOUT, COUNT, SKIP, SVR_SHADOW_REMARCH && DEPTH1>(s, L_, vs.pt, wiL, rng, sMin, sMax, sval, k + 1u < traceDepth, c);
+                float ts = walk<LAYOUT, COUNT, SKIP, SVR_SHADOW_REMARCH>(s, L_, vs.pt, wiL, rng, sMin, sMax, sval, k + 1u < traceDepth, c);
                 float Tr = ((ts > sMin) && (ts < sMax)) ? 0.f : 1.f;          // transmittance.h:15-16
                 float kf = Tr * (float)s.num_lights;
                 Ld = ((bsdf_eval(vs, wiL) * kf) * Li) / pdfL;

@@ -186,49 +186,58 @@ SVR_DEV int walk_setup(const DevScene& s, const LDS& L, v3 orig, v3 dir, bool rn
     return 1;
 }
 
-// REMARCH: when the walk comes out of an occupied region into clear space, march again (used for shadow
-// walks, which start inside the medium and would otherwise test every iteration of their way out)
+// REMARCH: a walk that comes out of an occupied stretch into clear space (two consecutive iterations in
+// deep-empty cells) PARKS: it leaves the iteration loop.  The lanes of a wave reconverge at the loop exit, so the
+// parked lanes march again TOGETHER (a per-lane march inside the loop is serialised by divergence and was
+// slower than not marching at all).  If nothing occupied lies ahead and no draw follows the walk, its result
+// (-FLT_MAX) is known; otherwise it resumes with the new t_occ.  COUNT builds keep iterating instead so that
+// the iteration/tap counters stay the reference's.
 template <int LAYOUT, bool COUNT, bool SKIP, bool REMARCH, typename LDS>
 SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float tMin, float tMax, float t_occ,
                        float& val, bool rng_live, Cnt& c)
 {
     float t = tMin;
-    uint32_t clear_run = 0;
     const bool ray_skippable = SKIP && s.ray_skip && !rng_live && t_occ == u2f(SVR_INF_BITS);
     if (COUNT && ray_skippable) c.wskip++;
-    bool tail_counted = false;          // COUNT builds only: the walk would have ended at a re-march
-    for (uint32_t guard = 0;; ++guard) {
-        if (COUNT) { c.iters++; if (ray_skippable) c.iskip++; else if (SKIP && t < t_occ && !tail_counted) c.ipre++; }
-        t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-        if (t > tMax || guard >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
-        if (COUNT) c.taps++;
-        float sigma_t = 0.f;
-        if (!SKIP || t >= t_occ) {
-            v3 p = orig + dir * t;
-            Cell cell = cell_of(s, p);
-            bool fetch = true;
-            if (SKIP) fetch = !cell_is_empty(L, s, cell);
-            if (fetch) {
-                if (COUNT) c.exec++;
-                val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
-                sigma_t = alpha_of(L, s, val);
-                clear_run = 0;
-            } else if (SKIP && REMARCH && s.ray_skip && ++clear_run == 2u) {
-                // second consecutive iteration in clear space (cell and neighbours transparent) after an occupied
-                // stretch: march again from here.  If nothing occupied lies ahead and no draw follows the walk,
-                // its result is known now.
-                t_occ = first_occupied(s, L, orig, dir, t, tMax);
-                if (t_occ == u2f(SVR_INF_BITS) && !rng_live) {
-                    if (!COUNT) return -SVR_FLT_MAX;
-                    if (!tail_counted) { tail_counted = true; c.wskip++; }
-                }
+    bool tail_counted = false;          // COUNT builds only: a non-counting build would have ended the walk
+    uint32_t guard = 0;
+    for (;;) {
+        bool parked = false;
+        uint32_t clear_run = 0;
+        float result = 0.f;
+        bool finished = false;
+        for (;; ++guard) {
+            if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; else if (SKIP && t < t_occ) c.ipre++; }
+            t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+            if (t > tMax || guard >= SVR_WALK_GUARD) { result = -SVR_FLT_MAX; finished = true; break; }
+            if (COUNT) c.taps++;
+            float sigma_t = 0.f;
+            bool park_now = false;
+            if (!SKIP || t >= t_occ) {
+                v3 p = orig + dir * t;
+                Cell cell = cell_of(s, p);
+                bool fetch = true;
+                if (SKIP) fetch = !cell_is_empty(L, s, cell);
+                if (fetch) {
+                    if (COUNT) c.exec++;
+                    val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
+                    sigma_t = alpha_of(L, s, val);
+                    clear_run = 0;
+                } else if (SKIP && REMARCH && ++clear_run == 2u) park_now = true;
             }
+            // the accept draw is consumed either way; with sigma_t == 0 it cannot accept (xi > 0)
+            if (rng_uniform(rng) < sigma_t * s.invSigmaMax) { result = t; finished = true; break; }
+            if (park_now) { parked = true; ++guard; break; }
         }
-        if (COUNT && tail_counted) c.iskip++;
-        // the accept draw is consumed either way; with sigma_t == 0 it cannot accept (xi > 0)
-        if (rng_uniform(rng) < sigma_t * s.invSigmaMax) break;
+        if (finished) return result;
+        // ---- parked lanes of the wave march together ----
+        (void)parked;
+        t_occ = first_occupied(s, L, orig, dir, t, tMax);
+        if (t_occ == u2f(SVR_INF_BITS) && !rng_live) {
+            if (!COUNT) return -SVR_FLT_MAX;
+            if (!tail_counted) { tail_counted = true; c.wskip++; }
+        }
     }
-    return t;
 }
 
 // sample_distance in one piece (tile kernel)
