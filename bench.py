@@ -226,6 +226,15 @@ def main():
                          "kernel_avg_ms": round(avg_ms, 4), "kernel_launches": k_n,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "vol_taps_per_path": round(loc["vol_taps"] / max(1, loc["paths"]), 3)})
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (committed under profiles/); it cannot be
+        # measured from inside this process
+        tfile = ROOT / "profiles" / f"r01_traffic_k_trace_tile_{args.scene}_s{S}.json"
+        if args.kernel in (0, 2) and world == 1 and tfile.exists():
+            try:
+                roof["traffic"] = json.loads(tfile.read_text())["traffic_bytes_per_launch"]
+                roof["traffic_source"] = str(tfile.relative_to(ROOT))
+            except Exception:
+                pass
         out = {
             "metric": "Msamples/sec (paths x spp) at 1024^2 on 512^3 volume",
             "value": round(value, 3),
