@@ -136,29 +136,38 @@ SVR_DEV float first_occupied(const DevScene& s, const LDS& L, v3 o, v3 d, float 
     float Ax = fma_(o.x - s.vmin[0], s.mc_scale[0], s.mc_off), Bx = d.x * s.mc_scale[0];
     float Ay = fma_(o.y - s.vmin[1], s.mc_scale[1], s.mc_off), By = d.y * s.mc_scale[1];
     float Az = fma_(o.z - s.vmin[2], s.mc_scale[2], s.mc_off), Bz = d.z * s.mc_scale[2];
-    int gx = s.mc_gx, gy = s.mc_gy, gz = s.mc_gz;
+    const int gx = s.mc_gx, gy = s.mc_gy, gz = s.mc_gz;
     int ix = min(max((int)__builtin_floorf(fma_(Bx, t0, Ax)), 0), gx - 1);
     int iy = min(max((int)__builtin_floorf(fma_(By, t0, Ay)), 0), gy - 1);
     int iz = min(max((int)__builtin_floorf(fma_(Bz, t0, Az)), 0), gz - 1);
-    int sx = Bx > 0.f ? 1 : -1, sy = By > 0.f ? 1 : -1, sz = Bz > 0.f ? 1 : -1;
+    const bool px = Bx > 0.f, py = By > 0.f, pz = Bz > 0.f;
     float rx = __builtin_amdgcn_rcpf(Bx), ry = __builtin_amdgcn_rcpf(By), rz = __builtin_amdgcn_rcpf(Bz);
-    float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
-    float tnx = (Bx != 0.f) ? ((float)(ix + (Bx > 0.f ? 1 : 0)) - Ax) * rx : INF;
-    float tny = (By != 0.f) ? ((float)(iy + (By > 0.f ? 1 : 0)) - Ay) * ry : INF;
-    float tnz = (Bz != 0.f) ? ((float)(iz + (Bz > 0.f ? 1 : 0)) - Az) * rz : INF;
-    dtx = (Bx != 0.f) ? dtx : INF; dty = (By != 0.f) ? dty : INF; dtz = (Bz != 0.f) ? dtz : INF;
+    // next face crossing and per-cell increment along each axis (+inf for an axis the ray does not move along)
+    float tnx = (Bx != 0.f) ? ((float)(ix + (px ? 1 : 0)) - Ax) * rx : INF;
+    float tny = (By != 0.f) ? ((float)(iy + (py ? 1 : 0)) - Ay) * ry : INF;
+    float tnz = (Bz != 0.f) ? ((float)(iz + (pz ? 1 : 0)) - Az) * rz : INF;
+    const float dtx = (Bx != 0.f) ? __builtin_fabsf(rx) : INF, dty = (By != 0.f) ? __builtin_fabsf(ry) : INF,
+                dtz = (Bz != 0.f) ? __builtin_fabsf(rz) : INF;
+    // linear cell index and its per-axis increments; cells left before the ray would step out of the grid
+    int q = ix + iy * gx + iz * s.mc_gxy;
+    const int qsx = px ? 1 : -1, qsy = py ? gx : -gx, qsz = pz ? s.mc_gxy : -s.mc_gxy;
+    int nx = px ? gx - 1 - ix : ix, ny = py ? gy - 1 - iy : iy, nz = pz ? gz - 1 - iz : iz;
     float t = t0;
     const uint32_t* deep = L.mask;
-    int guard = gx + gy + gz + 4;
+    const int guard = gx + gy + gz + 4;
     for (int it = 0; it < guard; ++it) {
-        uint32_t q = (uint32_t)ix + __umul24((uint32_t)iy, (uint32_t)gx) + __umul24((uint32_t)iz, (uint32_t)s.mc_gxy);
-        if (!((deep[q >> 5] >> (q & 31u)) & 1u)) return t;
+        if (!((deep[(uint32_t)q >> 5] >> ((uint32_t)q & 31u)) & 1u)) return t;
         float tn = fmin_(tnx, fmin_(tny, tnz));
         if (!(tn <= t1)) return INF;          // the segment ends inside this cell
         t = tn;
-        if (tnx <= tny && tnx <= tnz) { ix += sx; tnx += dtx; if ((uint32_t)ix >= (uint32_t)gx) return INF; }
-        else if (tny <= tnz) { iy += sy; tny += dty; if ((uint32_t)iy >= (uint32_t)gy) return INF; }
-        else { iz += sz; tnz += dtz; if ((uint32_t)iz >= (uint32_t)gz) return INF; }
+        // branch-free step along the axis of the nearest face
+        const bool sx = tnx <= tny && tnx <= tnz;
+        const bool sy = !sx && tny <= tnz;
+        const bool sz = !sx && !sy;
+        tnx += sx ? dtx : 0.f;  tny += sy ? dty : 0.f;  tnz += sz ? dtz : 0.f;
+        q += sx ? qsx : (sy ? qsy : qsz);
+        nx -= sx ? 1 : 0;  ny -= sy ? 1 : 0;  nz -= sz ? 1 : 0;
+        if ((nx | ny | nz) < 0) return INF;    // stepped out of the grid
     }
     return t;   // guard exhausted (cannot happen: each step leaves a cell): treat the rest as occupied
 }
