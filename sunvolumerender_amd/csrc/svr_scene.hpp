@@ -41,7 +41,7 @@ struct DevScene {
     int32_t bnx, bny;              // BRICK: bricks per row / per slab-row
     // empty-space bitmask (one bit per macro-cell of 2^mc_shift cells per axis; bit set = every
     // trilinear fetch whose cell lies in the macro-cell has transfer-function alpha exactly 0)
-    const uint32_t* empty_mask;    // device, mask_words words of deep-empty bits, or null (no skipping)
+    const uint32_t* empty_mask;    // device: mask_words words of deep-empty bits, then mask_words words of empty bits; null = no skipping
     int32_t mc_shift, mc_gx, mc_gy, mc_gz, mc_gxy;
     uint32_t mask_words;
     uint32_t ray_skip;             // 1: the clipped box lies inside the texture domain, so whole-ray tests are valid

@@ -8,11 +8,13 @@ namespace svr {
 
 struct LdsTile {
     float alpha[SVR_TF_MAX + SVR_TF_PAD];      // entry e = alpha of texel clamp(e-1)
-    uint32_t mask[MASK_WORDS_MAX];             // deep-empty bits: the macro-cell and its 26 neighbours are transparent
+    uint32_t mask[MASK_WORDS_MAX];             // deep-empty bits: the macro-cell and its 26 neighbours are transparent (ray march)
+    uint32_t emask[MASK_WORDS_MAX];            // empty bits: the macro-cell itself is transparent (per-fetch test, exact cell index)
 };
 struct LdsTileNoMask {
     float alpha[SVR_TF_MAX + SVR_TF_PAD];
     uint32_t mask[1];
+    uint32_t emask[1];
 };
 
 template <typename LDS>
@@ -27,6 +29,9 @@ SVR_DEV void lds_tile_load(LDS& L, const DevScene& s, bool with_mask)
         const uint4* src = reinterpret_cast<const uint4*>(s.empty_mask);
         uint4* dst = reinterpret_cast<uint4*>(L.mask);
         for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += blockDim.x) dst[q] = src[q];
+        const uint4* src2 = reinterpret_cast<const uint4*>(s.empty_mask + s.mask_words);
+        uint4* dst2 = reinterpret_cast<uint4*>(L.emask);
+        for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += blockDim.x) dst2[q] = src2[q];
     }
     __syncthreads();
 }
@@ -111,7 +116,8 @@ SVR_DEV float alpha_of(const LDS& L, const DevScene& s, float x)
 // macro-cell bit of a trilinear cell.  The mask covers the cells c = -1 .. N-1 (c+1 in [0, N]: every cell
 // a point of the texture domain maps to); cells further out (clip planes beyond the volume, gradient
 // taps) always fetch.
-template <typename LDS>
+// deep = false: the macro-cell is transparent (no fetch needed); deep = true: so are its 26 neighbours
+template <bool DEEP, typename LDS>
 SVR_DEV bool cell_is_empty(const LDS& L, const DevScene& s, const Cell& c)
 {
     uint32_t ux = (uint32_t)(c.cx + 1), uy = (uint32_t)(c.cy + 1), uz = (uint32_t)(c.cz + 1);
@@ -121,7 +127,7 @@ SVR_DEV bool cell_is_empty(const LDS& L, const DevScene& s, const Cell& c)
              qz = min(uz >> sh, (uint32_t)s.mc_gz - 1u);
     uint32_t m = qx + __umul24(qy, (uint32_t)s.mc_gx) + __umul24(qz, (uint32_t)s.mc_gxy);
     m = inb ? m : 0u;
-    uint32_t word = L.mask[m >> 5];
+    uint32_t word = DEEP ? L.mask[m >> 5] : L.emask[m >> 5];
     return inb && ((word >> (m & 31u)) & 1u);
 }
 
@@ -226,13 +232,17 @@ SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rn
                 v3 p = orig + dir * t;
                 Cell cell = cell_of(s, p);
                 bool fetch = true;
-                if (SKIP) fetch = !cell_is_empty(L, s, cell);
+                if (SKIP) fetch = !cell_is_empty<false>(L, s, cell);
                 if (fetch) {
                     if (COUNT) c.exec++;
                     val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
                     sigma_t = alpha_of(L, s, val);
                     clear_run = 0;
-                } else if (SKIP && REMARCH && ++clear_run == 2u) park_now = true;
+                } else if (SKIP && REMARCH) {
+                    // park after two consecutive iterations in DEEP-empty cells (where a march can start)
+                    clear_run = cell_is_empty<true>(L, s, cell) ? clear_run + 1u : 0u;
+                    park_now = clear_run == 2u;
+                }
             }
             // the accept draw is consumed either way; with sigma_t == 0 it cannot accept (xi > 0)
             if (rng_uniform(rng) < sigma_t * s.invSigmaMax) { result = t; finished = true; break; }

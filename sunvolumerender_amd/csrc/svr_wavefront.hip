@@ -240,7 +240,7 @@ __global__ __launch_bounds__(SVR_WF_WALK_THREADS, SVR_WF_WALK_WAVES_PER_EU) void
                 if (!SKIP || t >= rec.tw) {
                     Cell cell = cell_of(s, rec.a + rec.b * t);
                     bool fetch = true;
-                    if (SKIP) fetch = !cell_is_empty(lds, s, cell);
+                    if (SKIP) fetch = !cell_is_empty<false>(lds, s, cell);
                     if (fetch) {
                         if (COUNT) c.exec++;
                         val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
