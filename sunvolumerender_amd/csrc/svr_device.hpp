@@ -41,6 +41,18 @@ SVR_DEV float rng_uniform(Rng& r)
     return (float)x * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
 }
 
+// advance the generator by one draw whose value is not needed
+SVR_DEV void rng_skip(Rng& r)
+{
+    uint32_t t = r.v0 ^ (r.v0 >> 2);
+    r.v0 = r.v1;
+    r.v1 = r.v2;
+    r.v2 = r.v3;
+    r.v3 = r.v4;
+    r.v4 = (r.v4 ^ (r.v4 << 4)) ^ (t ^ (t << 1));
+    r.d += 362437u;
+}
+
 // pathtracer.cu:70-79 (host side too; see svr_api)
 __host__ __device__ inline uint32_t wang_hash(uint32_t a)
 {

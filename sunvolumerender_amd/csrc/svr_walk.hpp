@@ -217,18 +217,32 @@ SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rn
     bool tail_counted = false;          // COUNT builds only: a non-counting build would have ended the walk
     uint32_t guard = 0;
     for (;;) {
-        bool parked = false;
+        // ---- prefix: iterations before the first possibly-occupied macro-cell.  No fetch, sigma_t = 0: each is a
+        //      distance draw + log, the exit test, and the state update of the accept draw (its value is unused) ----
+        bool pending = false;           // t has been advanced and still needs its tap and accept draw
+        if (SKIP) {
+            for (;;) {
+                if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; else c.ipre++; }
+                t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+                if (t > tMax || guard++ >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
+                if (COUNT) c.taps++;
+                if (t >= t_occ) { pending = true; if (COUNT) { c.ipre -= !(ray_skippable || tail_counted); } break; }
+                rng_skip(rng);
+            }
+        }
+        // ---- general iterations (loop rotated: tap first, then advance) ----
         uint32_t clear_run = 0;
-        float result = 0.f;
-        bool finished = false;
-        for (;; ++guard) {
-            if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; else if (SKIP && t < t_occ) c.ipre++; }
-            t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-            if (t > tMax || guard >= SVR_WALK_GUARD) { result = -SVR_FLT_MAX; finished = true; break; }
-            if (COUNT) c.taps++;
+        for (;;) {
+            if (!pending) {
+                if (COUNT) { c.iters++; if (tail_counted) c.iskip++; }
+                t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+                if (t > tMax || guard++ >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
+                if (COUNT) c.taps++;
+            }
+            pending = false;
             float sigma_t = 0.f;
             bool park_now = false;
-            if (!SKIP || t >= t_occ) {
+            {
                 v3 p = orig + dir * t;
                 Cell cell = cell_of(s, p);
                 bool fetch = true;
@@ -245,12 +259,10 @@ SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rn
                 }
             }
             // the accept draw is consumed either way; with sigma_t == 0 it cannot accept (xi > 0)
-            if (rng_uniform(rng) < sigma_t * s.invSigmaMax) { result = t; finished = true; break; }
-            if (park_now) { parked = true; ++guard; break; }
+            if (rng_uniform(rng) < sigma_t * s.invSigmaMax) return t;
+            if (park_now) break;
         }
-        if (finished) return result;
         // ---- parked lanes of the wave march together ----
-        (void)parked;
         t_occ = first_occupied(s, L, orig, dir, t, tMax);
         if (t_occ == u2f(SVR_INF_BITS) && !rng_live) {
             if (!COUNT) return -SVR_FLT_MAX;
