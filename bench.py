@@ -4,9 +4,9 @@
 Workload (BASELINE.json metric: "Msamples/sec at 1024^2 on 512^3 volume"): config c3 = 512^3 CT-like
 volume, 1024^2 image, 3 area lights + environment map, GUI-default transfer function, trace depth 1
 (the reference's default, gui/canvas.cpp:17).  A *step* is one progressive-render pass over the whole
-frame: `--spp-per-step` samples for every pixel (default 8 = one frame group = one launch of the trace
-kernel through svr_render_pathtracer_frames, bit-identical to 8 render_pathtracer calls; the default
-32 steps are config c3's 256 spp; `--spp-per-step 1` is the reference's one-call-per-frame protocol).  With N GPUs the frame is sharded into interleaved 32-row strips
+frame: `--spp-per-step` samples for every pixel (default 32 = one frame group = one launch of the trace
+kernel through svr_render_pathtracer_frames, bit-identical to 32 render_pathtracer calls; the default
+8 steps are config c3's 256 spp; `--spp-per-step 1` is the reference's one-call-per-frame protocol).  With N GPUs the frame is sharded into interleaved 32-row strips
 (global per-pixel seeds, so the assembled image is bit-identical to one GPU) and the HDR accumulation
 buffers are summed onto rank 0 with one RCCL reduce per output, inside the timed region.
 
@@ -35,11 +35,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="c3")
     ap.add_argument("--trace-depth", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=32)
     ap.add_argument("--kernel", type=int, default=0, help="0 auto(=2), 1 block-per-tile baseline, 2 persistent tile kernel, 3 lane state machine")
     ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 linear, 2 brick")
     ap.add_argument("--blocks-per-cu", type=int, default=0)

@@ -21,6 +21,8 @@ struct LaunchCfg {
     bool count;
     int num_cus;
     int blocks_per_cu;     // persistent kernel
+    int unit_override;     // tile kernel: tasks per ticket (0 = heuristic)
+    int frames_log2;       // tile kernel: log2(frames per wave), -1 = as many as the group allows (<= 8)
 };
 
 // trace work.nframes paths per owned pixel into the scratch slots work.lbuf

@@ -144,8 +144,16 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = w.x1 - w.x0;
-    const uint32_t tiles_x = (wv + 7u) >> 3;
-    const uint32_t n_tasks = tiles_x * ((w.n_rows + 7u) >> 3) * w.nframes;
+    // Lanes of a wave = (64 >> fl2) pixels x (1 << fl2) frames of the group: rays of one pixel in different frames
+    // share origin, box segment and whole-ray test result up to sub-pixel jitter, so a wave is far more uniform
+    // (skip / walk / hit, walk lengths) than 64 different pixels of one frame, and it touches fewer bricks.
+    const uint32_t fl2 = w.frames_log2;                       // 0..6
+    const uint32_t P2 = 6u - fl2;                             // log2(pixels per wave)
+    const uint32_t tw2 = (P2 + 1u) >> 1, th2 = P2 >> 1;       // pixel block 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
+    const uint32_t tiles_x = (wv + (1u << tw2) - 1u) >> tw2;
+    const uint32_t tiles_y = (w.n_rows + (1u << th2) - 1u) >> th2;
+    const uint32_t fgroups = (w.nframes + (1u << fl2) - 1u) >> fl2;
+    const uint32_t n_tasks = tiles_x * tiles_y * fgroups;
     Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // Work distribution.  A single returning atomic saturates near 88 dequeues/us chip-wide
@@ -173,12 +181,14 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
             const uint32_t t_end = min(t_begin + unit, n_tasks);
             for (uint32_t task = t_begin; task < t_end; ++task) {
                 if (COUNT) c.loops += (lane == 0);
-                uint32_t tile = task / w.nframes;
-                uint32_t slot = task - tile * w.nframes;
+                uint32_t tile = task / fgroups;
+                uint32_t fg = task - tile * fgroups;
                 uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-                uint32_t px = (tx << 3) + (lane & 7u);
-                uint32_t r = (ty << 3) + (lane >> 3);
-                if (px < wv && r < w.n_rows) {
+                uint32_t pl = lane & ((1u << P2) - 1u);
+                uint32_t slot = (fg << fl2) + (lane >> P2);
+                uint32_t px = (tx << tw2) + (pl & ((1u << tw2) - 1u));
+                uint32_t r = (ty << th2) + (pl >> tw2);
+                if (px < wv && r < w.n_rows && slot < w.nframes) {
                     uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
                     v3 L = trace_path_tile<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, x, y, w.traceDepth, wang_hash(w.frame0 + slot), w.debug_stop, c);
                     float* o = w.lbuf + (size_t)slot * w.slot_stride + 3 * ((size_t)y * s.imageW + x);
@@ -195,19 +205,27 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
 {
     uint32_t wv = w.x1 - w.x0;
     if (wv == 0 || w.n_rows == 0) return hipSuccess;
-    uint32_t n_tasks = ((wv + 7u) >> 3) * ((w.n_rows + 7u) >> 3) * w.nframes;
+    // frames per wave: the largest power of two <= min(nframes, 64), unless overridden
+    uint32_t fl2 = 0;
+    while (fl2 < 6u && (2u << fl2) <= w.nframes) ++fl2;
+    if (cfg.frames_log2 >= 0 && (uint32_t)cfg.frames_log2 < fl2) fl2 = (uint32_t)cfg.frames_log2;
+    const uint32_t P2 = 6u - fl2, tw2 = (P2 + 1u) >> 1, th2 = P2 >> 1;
+    const uint32_t fgroups = (w.nframes + (1u << fl2) - 1u) >> fl2;
+    uint32_t n_tasks = ((wv + (1u << tw2) - 1u) >> tw2) * ((w.n_rows + (1u << th2) - 1u) >> th2) * fgroups;
     constexpr uint32_t WPB = SVR_TILE_THREADS / 64;                       // waves per block
     uint32_t max_blocks = (uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / WPB;
     uint32_t need = (n_tasks + WPB - 1u) / WPB;
     uint32_t blocks = need < max_blocks ? need : max_blocks;
     if (blocks == 0) blocks = 1;
-    // ticket unit: about 4 units per wave for balance, never more than one tile's frames
+    // ticket unit: ONE task.  Task costs differ by two orders of magnitude (a block of skipped rays vs a block of
+    // grazing rays), so coarser units leave most waves idle behind the last heavy unit: measured 0.183 / 0.189 /
+    // 0.208 / 0.230 / 0.279 ms per frame at 1 / 2 / 4 / 8 / 16 tasks per ticket (8-frame groups).  With 8 ticket
+    // shards the atomics are not a limit (~130 k per launch).
     DevWork w2 = w;
-    uint32_t waves = blocks * WPB;
-    uint32_t unit = n_tasks / (waves * 4u);
-    if (unit > w.nframes) unit = w.nframes;
-    if (unit < 1u) unit = 1u;
+    uint32_t unit = 1u;
+    if (cfg.unit_override > 0) unit = (uint32_t)cfg.unit_override;
     w2.unit = unit;
+    w2.frames_log2 = fl2;
     hipError_t e = hipMemsetAsync(w.ticket, 0, sizeof(uint32_t) * TICKET_SHARDS * TICKET_STRIDE, st);
     if (e != hipSuccess) return e;
     const bool skip = s.empty_mask != nullptr, d1 = w.traceDepth == 1u;

@@ -50,14 +50,16 @@ def test_pathtracer_bit_exact(hip_dev, name, depth, frames, kernel, skip, kid, l
 
 
 def test_batch_equals_sequential(hip_dev):
-    """svr_render_pathtracer_frames(n) is bit-identical to n render_pathtracer calls (groups of 8 + remainder)."""
+    """svr_render_pathtracer_frames(n) is bit-identical to n render_pathtracer calls (one group of 32 + remainder;
+    lanes of a wave = pixels x frames in the batch form)."""
     sc = scenes.make_scene("tiny_head", trace_depth=2)
-    a_hdr, a_img, _ = hip_frames(hip_dev, sc, 11, batch=False)
-    b_hdr, b_img, _ = hip_frames(hip_dev, sc, 11, batch=True)
-    c_hdr, c_img, _ = hip_frames(hip_dev, sc, 11, batch=True, pipeline=False)
+    n = 37
+    a_hdr, a_img, _ = hip_frames(hip_dev, sc, n, batch=False)
+    b_hdr, b_img, _ = hip_frames(hip_dev, sc, n, batch=True)
+    c_hdr, c_img, _ = hip_frames(hip_dev, sc, n, batch=True, pipeline=False)
     assert_bit_exact(a_hdr, b_hdr, "batch vs sequential")
     assert_bit_exact(a_hdr, c_hdr, "pipelined vs single stream")
     assert np.array_equal(a_img, b_img) and np.array_equal(a_img, c_img)
-    ref_hdr, ref_img, _ = oracle_frames(sc, 11)
-    assert_bit_exact(a_hdr, ref_hdr, "11 frames vs oracle")
+    ref_hdr, ref_img, _ = oracle_frames(sc, n)
+    assert_bit_exact(a_hdr, ref_hdr, f"{n} frames vs oracle")
     assert np.array_equal(a_img, ref_img)

@@ -15,6 +15,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="c3")
 ap.add_argument("--frames", type=int, default=16)
 ap.add_argument("--depth", type=int, default=1)
+ap.add_argument("--fl2", type=int, default=-1, help="log2 frames per wave (-1 auto)")
+ap.add_argument("--unit", type=int, default=0)
 ap.add_argument("--stop", type=int, default=0, help="timing ablation: 1 set-up only, 2 +whole-ray test, 3 +primary walk")
 ap.add_argument("combos", nargs="+")
 a = ap.parse_args()
@@ -22,6 +24,8 @@ a = ap.parse_args()
 sc = scenes.make_scene(a.scene, trace_depth=a.depth)
 dev = host.Device(0)
 dev.set_option(100, a.stop)
+dev.set_option(101, a.unit)
+dev.set_option(abi.OPT_FRAMES_PER_WAVE_LOG2, a.fl2)
 print("stop:", a.stop, "lib:", abi.library_path().name, "|", dev.info(), flush=True)
 canv = {}
 for combo in a.combos:
