@@ -214,3 +214,47 @@ def test_c3_properties(hip_dev, c3_canvas):
     got = hip_dev.to_host(img2, (sc.height, sc.width, 4), np.uint8)
     hip_dev.free(img2)
     assert np.array_equal(got, one_img)
+
+
+def _odd_scene(depth=2):
+    """Non-cubic volume, anisotropic spacing, image size not a multiple of the tile size, off-axis camera,
+    thin-lens aperture, density scale and clip planes all at once."""
+    rs = np.random.RandomState(5)
+    base = scenes.make_ct_head_volume(64)
+    vox = np.ascontiguousarray(base[8:40, 4:60, 12:52])           # nz=32, ny=56, nx=40
+    spacing = (1.0, 0.5, 2.0)
+    tf, mo = scenes.bone_transfer_function()
+    nx, ny, nz = vox.shape[2], vox.shape[1], vox.shape[0]
+    W, H = 50, 37
+    cam = host.camera_setup((30.0, 22.0, 95.0), (1.0, -2.0, 0.5), (0.1, 1.0, 0.0), 40.0, 0.8, 1.3, 1.5, W, H)
+    R = host.bounding_sphere_radius((nx, ny, nz), spacing)
+    lights = [host.place_area_light(20.0, 30.0, R * 1.5 + 1, 6.0, (1.0, 0.9, 0.8), 700.0),
+              host.place_area_light(-70.0, -40.0, R * 1.5 + 1, 9.0, (0.7, 0.8, 1.0), 900.0)]
+    return scenes.Scene(name="odd", vox=vox, spacing=spacing, max_magnitude=scenes.max_gradient_magnitude(vox, spacing),
+                        tf_rgba=tf, max_opacity=mo, width=W, height=H, lights=lights, env_map=scenes.synthetic_env_map(64, 32),
+                        env_offset=(0.3, 0.1), env_on_escape=True, trace_depth=depth, density_scale=1.2, gradient_factor=0.8,
+                        clip=((-0.9, 1.0), (-1.0, 0.85), (-0.7, 1.0)), camera=cam)
+
+
+@pytest.mark.parametrize("kernel", [abi.KERNEL_TILE, abi.KERNEL_PIXEL, abi.KERNEL_WAVEFRONT, abi.KERNEL_ULOOP],
+                         ids=["tile", "pixel", "wavefront", "uloop"])
+def test_non_cubic_anisotropic_scene(hip_dev, kernel):
+    sc = _odd_scene()
+    ref_hdr, ref_img, ref_c = oracle_frames(sc, 3)
+    for layout in (abi.LAYOUT_BRICK, abi.LAYOUT_LINEAR):
+        hdr, img, c = hip_frames(hip_dev, sc, 3, kernel=kernel, layout=layout)
+        assert_bit_exact(hdr, ref_hdr, f"odd scene kernel {kernel} layout {layout}")
+        assert np.array_equal(img, ref_img)
+        assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"]
+    b_hdr, b_img, _ = hip_frames(hip_dev, sc, 3, kernel=kernel, batch=True)
+    assert_bit_exact(b_hdr, ref_hdr, "odd scene, batch")
+    # ray caster on the same scene
+    ref_rc, _ = binding.OracleScene(sc).render_raycasting()
+    canvas = host.Canvas(hip_dev, sc.width, sc.height)
+    try:
+        scenes.apply_to_canvas(sc, canvas)
+        canvas.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING)
+        canvas.paint(sync=True)
+        assert np.array_equal(canvas.read_img(), ref_rc)
+    finally:
+        canvas.close()
