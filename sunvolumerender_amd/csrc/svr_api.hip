@@ -342,24 +342,24 @@ void collect_timing()
 
 // (Re)build the empty-space bitmask when the volume, the transfer-function table or densityScale
 // changed.  Scene edits are rare (UI events), so the rebuild simply drains the device first.
-int ensure_mask(svr::DevScene& s)
+int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_function& tf)
 {
     s.empty_mask = nullptr;
     if (!g.opt_empty_skip) return 0;
-    Texture* tv = find_tex(g.vol.tex, TEX_VOLUME);
-    Texture* tt = find_tex(g.tf.tex, TEX_TF);
+    Texture* tv = find_tex(vol.tex, TEX_VOLUME);
+    Texture* tt = find_tex(tf.tex, TEX_TF);
     if (!tv || !tt || !tv->mm || !tt->zero_prefix) return 0;
     uint32_t ds_bits;
-    memcpy(&ds_bits, &g.vol.densityScale, 4);
+    memcpy(&ds_bits, &vol.densityScale, 4);
     uint32_t n_cells = (uint32_t)tv->mc_gx * (uint32_t)tv->mc_gy * (uint32_t)tv->mc_gz;
     uint32_t words = (n_cells + 31u) / 32u;
-    if (!(g.mask_valid && g.mask_vol == g.vol.tex && g.mask_tf == g.tf.tex && g.mask_tf_version == tt->version &&
+    if (!(g.mask_valid && g.mask_vol == vol.tex && g.mask_tf == tf.tex && g.mask_tf_version == tt->version &&
           g.mask_ds_bits == ds_bits)) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(svr::launch_empty_mask(tv->mm, tv->mc_gx, tv->mc_gy, tv->mc_gz, tt->zero_prefix, tt->nx,
-                                       g.vol.densityScale, g.d_mask, words, g.stream));
+                                       vol.densityScale, g.d_mask, words, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        g.mask_valid = true; g.mask_vol = g.vol.tex; g.mask_tf = g.tf.tex; g.mask_tf_version = tt->version;
+        g.mask_valid = true; g.mask_vol = vol.tex; g.mask_tf = tf.tex; g.mask_tf_version = tt->version;
         g.mask_ds_bits = ds_bits; g.mask_words = words;
     }
     s.empty_mask = g.d_mask;
@@ -375,8 +375,8 @@ int ensure_mask(svr::DevScene& s)
     s.mc_off = 0.5f * invS;
     // whole-ray tests need every fetch of a walk inside the texture domain: clipped box within the bbox
     bool inside = true;
-    const float lo[3] = {g.vol.bbox.vmin.x, g.vol.bbox.vmin.y, g.vol.bbox.vmin.z};
-    const float hi[3] = {g.vol.bbox.vmax.x, g.vol.bbox.vmax.y, g.vol.bbox.vmax.z};
+    const float lo[3] = {vol.bbox.vmin.x, vol.bbox.vmin.y, vol.bbox.vmin.z};
+    const float hi[3] = {vol.bbox.vmax.x, vol.bbox.vmax.y, vol.bbox.vmax.z};
     for (int a = 0; a < 3; ++a) {
         float cl = s.clip_vmin[a] < s.clip_vmax[a] ? s.clip_vmin[a] : s.clip_vmax[a];
         float ch = s.clip_vmin[a] < s.clip_vmax[a] ? s.clip_vmax[a] : s.clip_vmin[a];
@@ -434,7 +434,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     if (ensure_slots(s.imageW, s.imageH, nframes < (uint32_t)Context::GROUP ? nframes : (uint32_t)Context::GROUP)) return g.err_code;
     svr::LaunchCfg cfg;
     cfg.kernel = g.opt_kernel == svr::KERNEL_AUTO ? svr::KERNEL_TILE : g.opt_kernel;
-    if ((cfg.kernel == svr::KERNEL_TILE || cfg.kernel == svr::KERNEL_WAVEFRONT) && ensure_mask(s)) return g.err_code;
+    if ((cfg.kernel == svr::KERNEL_TILE || cfg.kernel == svr::KERNEL_WAVEFRONT) && ensure_mask(s, g.vol, g.tf)) return g.err_code;
     if (cfg.kernel == svr::KERNEL_WAVEFRONT) {
         if (rp->traceDepth > 15) return fail(-3, "the wavefront kernels support traceDepth <= 15 (got %u)", rp->traceDepth);
         if (ensure_queues(s.imageW, s.imageH)) return g.err_code;
@@ -807,6 +807,7 @@ void render_raycasting(void* img, svr_volume* volume, svr_transfer_function* tra
     svr::DevWork w;
     fill_work(w, s.imageW, s.imageH);
     w.img = (uint8_t*)img;
+    if (ensure_mask(s, *volume, *transferFunction)) return;
     hipError_t e = svr::launch_raycast(s, w, stepSize, g.opt_count != 0, g.stream);
     if (e != hipSuccess) fail((int)e, "render_raycasting launch failed: %s", hipGetErrorName(e));
 }

@@ -11,7 +11,7 @@
 //                          LDS.  A path's arithmetic does not depend on scheduling, so both
 //                          kernels give bit-identical radiance.
 //  k_tonemap               hdr_to_ldr (pathtracer.cu:282-290)
-//  k_raycast               kernel_raycasting (raycasting.cu:15-67)
+//  (k_raycast lives in svr_raycast.hip)
 //  k_repack_*              [z][y][x] u16 -> padded LINEAR / BRICK software-texture layouts
 #include "svr_kernel_common.hpp"
 
@@ -459,66 +459,6 @@ __global__ __launch_bounds__(256) void k_tonemap(const DevScene s, const DevWork
 }
 
 // ------------------------------------------------------------------------------------------
-// kernel_raycasting, raycasting.cu:15-67
-// ------------------------------------------------------------------------------------------
-template <int LAYOUT, bool COUNT>
-__global__ __launch_bounds__(256) void k_raycast(const DevScene s, const DevWork w, float stepSize)
-{
-    __shared__ LdsTF tf;
-    lds_tf_load(tf, s);
-    uint32_t wv = w.x1 - w.x0;
-    uint32_t tiles16_x = (wv + 15u) >> 4;
-    uint32_t bty = blockIdx.x / tiles16_x, btx = blockIdx.x - bty * tiles16_x;
-    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t px = (btx << 4) + ((wave & 1u) << 3) + (lane & 7u);
-    uint32_t r = (bty << 4) + ((wave >> 1) << 3) + (lane >> 3);
-    uint32_t steps = 0;
-    if (px < wv && r < w.n_rows) {
-        uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
-        v3 orig, dir;
-        camera_ray_pinhole(s, x, y, orig, dir);
-        float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
-        float tNear, tFar;
-        if (volume_intersect(s, orig, dir, tNear, tFar)) {
-            float t = tNear;
-            while (t <= tFar) {
-                steps++;
-                v3 p = orig + dir * t;
-                float intensity = volume_intensity<LAYOUT>(s, p);
-                float co[4];
-                lds_tf_rgba(tf, s, intensity, co);
-                v3 gradient = volume_gradient<LAYOUT>(s, p);
-                float gm = __builtin_sqrtf(dot(gradient, gradient));
-                float cosTerm = 1.f, specularTerm = 0.f;
-                if ((double)gm > 1e-3) {
-                    v3 normal = normalize(gradient);
-                    v3 lightDir = normalize(V3(s.cam_pos[0], s.cam_pos[1], s.cam_pos[2]) - p);
-                    cosTerm = __builtin_fabsf(dot(normal, lightDir));
-                    specularTerm = powf_(cosTerm, 30.f);
-                }
-                co[0] = co[0] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
-                co[1] = co[1] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
-                co[2] = co[2] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
-                float wgt = 1.f - La;
-                Lr += wgt * co[0]; Lg += wgt * co[1]; Lb += wgt * co[2]; La += wgt * co[3];
-                if (La > 0.95f) break;
-                t += stepSize * 0.5f;
-            }
-        }
-        Lr = fmin_(Lr, 1.f); Lg = fmin_(Lg, 1.f); Lb = fmin_(Lb, 1.f);
-        uint32_t rgba = to_u8(Lr * 255) | (to_u8(Lg * 255) << 8) | (to_u8(Lb * 255) << 16) | (to_u8(255 * La) << 24);
-        reinterpret_cast<uint32_t*>(w.img)[(size_t)y * s.imageW + x] = rgba;
-    }
-    if (COUNT) {
-        unsigned long long st = wave_sum(steps), tp = wave_sum((unsigned long long)steps * 7ull);
-        if (lane == 0) {
-            atomicAdd(&w.counters[CNT_RAYCAST], st);
-            atomicAdd(&w.counters[CNT_VOL_TAPS], tp);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // volume repack: dst must be zero-filled (apron) before the launch
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_repack(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
@@ -587,21 +527,6 @@ hipError_t launch_tonemap(const DevScene& s, const DevWork& w, hipStream_t st)
     if (w.n_items == 0) return hipSuccess;
     uint32_t blocks = (w.n_items + 255u) / 256u;
     hipLaunchKernelGGL(k_tonemap, dim3(blocks), dim3(256), 0, st, s, w);
-    return hipGetLastError();
-}
-
-hipError_t launch_raycast(const DevScene& s, const DevWork& w, float stepSize, bool count, hipStream_t st)
-{
-    uint32_t wv = w.x1 - w.x0;
-    if (wv == 0 || w.n_rows == 0) return hipSuccess;
-    uint32_t blocks = ((wv + 15u) >> 4) * ((w.n_rows + 15u) >> 4);
-    if (s.layout == LAYOUT_LINEAR) {
-        if (count) hipLaunchKernelGGL((k_raycast<LAYOUT_LINEAR, true>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
-        else hipLaunchKernelGGL((k_raycast<LAYOUT_LINEAR, false>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
-    } else {
-        if (count) hipLaunchKernelGGL((k_raycast<LAYOUT_BRICK, true>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
-        else hipLaunchKernelGGL((k_raycast<LAYOUT_BRICK, false>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
-    }
     return hipGetLastError();
 }
 

@@ -2,6 +2,7 @@
 scene edits through the Canvas protocol, error behaviour, and size-independent properties at the full
 benchmark size (c3: 512^3 volume, 1024^2 image)."""
 import ctypes as C
+import dataclasses
 from pathlib import Path
 
 import numpy as np
@@ -258,3 +259,42 @@ def test_non_cubic_anisotropic_scene(hip_dev, kernel):
         assert np.array_equal(canvas.read_img(), ref_rc)
     finally:
         canvas.close()
+
+
+def _inside_scene():
+    """Camera inside the volume (tNear = 0: the first sample sits exactly at the eye, where the head-light
+    direction of raycasting.cu:45 is 0/0)."""
+    sc = scenes.make_scene("tiny_head")
+    cam = host.camera_setup((3.0, -2.0, 5.0), (0.0, 1.0, -4.0), (0.0, 1.0, 0.0), 60.0, 0.0, 1.0, 1.0, sc.width, sc.height)
+    return dataclasses.replace(sc, name="inside", camera=cam)
+
+
+@pytest.mark.parametrize("skip", [1, 0], ids=["skip", "noskip"])
+@pytest.mark.parametrize("layout", [abi.LAYOUT_LINEAR, abi.LAYOUT_BRICK], ids=["linear", "brick"])
+@pytest.mark.parametrize("case", ["tiny_bone", "odd", "inside"])
+def test_raycasting_cases(hip_dev, case, layout, skip):
+    """Empty-space skipping in k_raycast drops samples whose opacity is exactly 0; the image and the step
+    count must not change, with the bitmask on or off."""
+    sc = {"tiny_bone": lambda: scenes.make_scene("tiny_bone"), "odd": _odd_scene, "inside": _inside_scene}[case]()
+    ref, rc = binding.OracleScene(sc).render_raycasting()
+    canvas = host.Canvas(hip_dev, sc.width, sc.height)
+    try:
+        scenes.apply_to_canvas(sc, canvas, layout)
+        canvas.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING)
+        hip_dev.set_option(abi.OPT_EMPTY_SKIP, skip)
+        hip_dev.set_option(abi.OPT_COUNT, 1)
+        hip_dev.reset_counters()
+        canvas.paint(sync=True)
+        img = canvas.read_img()
+        cnt = hip_dev.counters()
+    finally:
+        hip_dev.set_option(abi.OPT_COUNT, 0)
+        hip_dev.set_option(abi.OPT_EMPTY_SKIP, 1)
+        canvas.close()
+    assert np.array_equal(img, ref)
+    assert cnt["raycast_steps"] == rc["raycast_steps"]
+    assert cnt["vol_taps"] == 7 * rc["raycast_steps"]
+    if skip:
+        assert cnt["vol_taps_executed"] < cnt["vol_taps"]
+    else:
+        assert cnt["vol_taps_executed"] == cnt["vol_taps"]

@@ -17,5 +17,5 @@ for _ in range(n):
 dev.synchronize()
 dt = (time.perf_counter() - t0) / n
 dev.set_option(abi.OPT_COUNT, 1); dev.reset_counters(); c.paint(sync=True); cnt = dev.counters()
-print(f"raycast {name}: {dt*1e3:.3f} ms/frame  {sc.width*sc.height/dt/1e6:.1f} Mpix/s  steps={cnt['raycast_steps']}")
+print(f"raycast {name}: {dt*1e3:.3f} ms/frame  {sc.width*sc.height/dt/1e6:.1f} Mpix/s  steps={cnt['raycast_steps']} taps_executed={cnt['vol_taps_executed']} of {cnt['vol_taps']}")
 c.close()
