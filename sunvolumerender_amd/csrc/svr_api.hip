@@ -96,7 +96,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     bool mask_valid = false;
@@ -808,7 +808,7 @@ void render_raycasting(void* img, svr_volume* volume, svr_transfer_function* tra
     fill_work(w, s.imageW, s.imageH);
     w.img = (uint8_t*)img;
     if (ensure_mask(s, *volume, *transferFunction)) return;
-    hipError_t e = svr::launch_raycast(s, w, stepSize, g.opt_count != 0, g.stream);
+    hipError_t e = svr::launch_raycast(s, w, stepSize, g.opt_count != 0, g.num_cus, g.opt_rc_lanes, g.stream);
     if (e != hipSuccess) fail((int)e, "render_raycasting launch failed: %s", hipGetErrorName(e));
 }
 
@@ -846,6 +846,9 @@ int svr_set_option(int key, int value)
     case SVR_OPT_RAY_SKIP: g.opt_ray_skip = value ? 1 : 0; return 0;
     case 100: g.opt_debug_stop = value; return 0;      // undocumented timing ablation (wrong images)
     case 101: g.opt_unit = value; return 0;            // undocumented: tasks per ticket of the tile kernel
+    case SVR_OPT_RAYCAST_LANES_LOG2:
+        if (value < 0 || value > 5) return fail(-6, "SVR_OPT_RAYCAST_LANES_LOG2: bad value %d (0..5)", value);
+        g.opt_rc_lanes = value; return 0;
     case SVR_OPT_FRAMES_PER_WAVE_LOG2:
         if (value < -1 || value > 6) return fail(-6, "SVR_OPT_FRAMES_PER_WAVE_LOG2: bad value %d (-1..6)", value);
         g.opt_frames_log2 = value; return 0;
@@ -869,6 +872,8 @@ int svr_get_option(int key)
     case SVR_OPT_EMPTY_SKIP: return g.opt_empty_skip;
     case SVR_OPT_RAY_SKIP: return g.opt_ray_skip;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
+    case SVR_OPT_FRAMES_PER_WAVE_LOG2: return g.opt_frames_log2;
+    case SVR_OPT_RAYCAST_LANES_LOG2: return g.opt_rc_lanes;
     default: return -1;
     }
 }

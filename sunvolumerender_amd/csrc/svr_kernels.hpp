@@ -45,7 +45,7 @@ hipError_t launch_empty_mask(const uint16_t* mm, int gx, int gy, int gz, const u
 // hdr_to_ldr over the owned pixels
 hipError_t launch_tonemap(const DevScene& scene, const DevWork& work, hipStream_t stream);
 // kernel_raycasting over the owned pixels
-hipError_t launch_raycast(const DevScene& scene, const DevWork& work, float stepSize, bool count, hipStream_t stream);
+hipError_t launch_raycast(const DevScene& scene, const DevWork& work, float stepSize, bool count, int num_cus, int lanes_log2, hipStream_t stream);
 // repack a [nz][ny][nx] u16 volume (device) into the padded LINEAR or BRICK layout (device)
 hipError_t launch_repack(const uint16_t* src, uint16_t* dst, int nx, int ny, int nz, int layout,
                          int sy, int sz, int bnx, int bny, hipStream_t stream);

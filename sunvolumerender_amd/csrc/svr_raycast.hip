@@ -1,17 +1,27 @@
 // svr_raycast.hip -- kernel_raycasting (raycasting.cu:15-67): front-to-back emission/absorption
 // compositing with a head-light Phong term, fixed step stepSize/2, early exit at opacity > 0.95.
 //
-// One thread per owned pixel, 16x16-pixel blocks of four 8x8 waves.  The RGBA transfer function and
-// the `empty` macro-cell bitmask (svr_accel.hip) live in LDS.  A sample whose trilinear cell lies in
-// an empty macro-cell has opacity exactly 0, so its contribution to (L.rgb, L.a) is exactly +0 and
-// the sample -- its intensity tap, six gradient taps, TF lookup and shading -- is skipped; only the
-// float accumulation t += h is kept, so the sample positions stay those of the reference.  In a
-// non-empty macro-cell the intensity tap and the opacity lookup decide the same way (opacity == 0:
-// no gradient, no shading).  Each lane first advances to its next contributing sample in a cheap
-// loop, then the wave shades together.  (Transfer-function colours are assumed finite.)
+// The reference runs one thread per pixel; a frame then takes as long as its longest ray (~1200 shaded
+// samples of ~1200 instructions each through a translucent 512^3 volume: 5 ms), with the chip almost
+// empty behind it.  Here S = 2^SL2 adjacent lanes share one ray: lane j evaluates the samples
+// n = j, j+S, j+2S ... (the sample parameters are the reference's float chain t += h, replayed by every
+// lane), and the S colours of a chunk are composited in order by all S lanes redundantly, so the
+// accumulation L += (1 - L.a) * c is the reference's, sample by sample.  Samples past the early exit are
+// evaluated speculatively and dropped.
+//
+// Empty space: a sample whose trilinear cell lies in an `empty` macro-cell (svr_accel.hip, bitmask in
+// LDS), or whose opacity lookup returns exactly 0, contributes exactly +0 to (L.rgb, L.a), so its six
+// gradient taps and the shading are skipped (the first kind also skips the intensity tap).  Each ray
+// first advances chunk by chunk through such samples in a cheap loop; the wave shades when every ray
+// of the wave has a contributing sample pending (or has finished).  Transfer-function colours are
+// assumed finite (0 * inf would differ).
+//
+// Persistent 512-thread blocks pull tasks (64 >> SL2 pixels each) from sharded tickets, as k_trace_tile.
 #include "svr_walk.hpp"
 
 namespace svr {
+
+#define SVR_RC_THREADS 512
 
 struct LdsRaycast {
     float4 rgba[SVR_TF_MAX + SVR_TF_PAD];      // entry e = texel clamp(e-1)
@@ -19,95 +29,175 @@ struct LdsRaycast {
     uint32_t emask[MASK_WORDS_MAX];
 };
 
-template <int LAYOUT, bool COUNT, bool SKIP>
-__global__ __launch_bounds__(256) void k_raycast(const DevScene s, const DevWork w, float stepSize)
+template <int LAYOUT, bool COUNT, bool SKIP, int SL2>
+__global__ __launch_bounds__(SVR_RC_THREADS) void k_raycast(const DevScene s, const DevWork w, float stepSize)
 {
+    constexpr uint32_t S = 1u << SL2;                  // lanes per ray
+    constexpr uint32_t P2 = 6u - SL2;                  // log2(rays per wave)
+    constexpr uint32_t tw2 = P2 < 3u ? P2 : 3u, th2 = P2 - tw2;   // pixel block of a task: up to 8 wide
+    constexpr uint32_t GMASK = S == 32u ? 0xffffffffu : ((1u << S) - 1u);
+    static_assert(SL2 >= 0 && SL2 <= 5, "1..32 lanes per ray");
+
     __shared__ LdsRaycast L;
     {
         const int n = s.tf_n;
         const float4* g = reinterpret_cast<const float4*>(s.tf);
-        for (int e = threadIdx.x; e < n + SVR_TF_PAD; e += 256) L.rgba[e] = g[min(max(e - 1, 0), n - 1)];
+        for (int e = threadIdx.x; e < n + SVR_TF_PAD; e += SVR_RC_THREADS) L.rgba[e] = g[min(max(e - 1, 0), n - 1)];
         if (SKIP) {
             const uint4* src = reinterpret_cast<const uint4*>(s.empty_mask + s.mask_words);
             uint4* dst = reinterpret_cast<uint4*>(L.emask);
-            for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += 256u) dst[q] = src[q];
+            for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += SVR_RC_THREADS) dst[q] = src[q];
         }
         __syncthreads();
     }
-    uint32_t wv = w.x1 - w.x0;
-    uint32_t tiles16_x = (wv + 15u) >> 4;
-    uint32_t bty = blockIdx.x / tiles16_x, btx = blockIdx.x - bty * tiles16_x;
-    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t px = (btx << 4) + ((wave & 1u) << 3) + (lane & 7u);
-    uint32_t r = (bty << 4) + ((wave >> 1) << 3) + (lane >> 3);
-    uint32_t steps = 0, shaded = 0, fetched = 0;
-    if (px < wv && r < w.n_rows) {
-        uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
-        v3 orig, dir;
-        camera_ray_pinhole(s, x, y, orig, dir);
-        const v3 cam = V3(s.cam_pos[0], s.cam_pos[1], s.cam_pos[2]);
-        float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
-        float tNear, tFar;
-        if (volume_intersect(s, orig, dir, tNear, tFar)) {
-            const float h = stepSize * 0.5f;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t j = lane & (S - 1u), ray = lane >> SL2, gshift = ray << SL2;
+    const uint32_t wv = w.x1 - w.x0;
+    const uint32_t tiles_x = (wv + (1u << tw2) - 1u) >> tw2;
+    const uint32_t tiles_y = (w.n_rows + (1u << th2) - 1u) >> th2;
+    const uint32_t n_tasks = tiles_x * tiles_y;
+    const uint32_t per_shard = (n_tasks + TICKET_SHARDS - 1u) / TICKET_SHARDS;
+    const uint32_t shard0 = blockIdx.x % TICKET_SHARDS;
+    const v3 cam = V3(s.cam_pos[0], s.cam_pos[1], s.cam_pos[2]);
+    const float h = stepSize * 0.5f;
+    uint32_t n_steps = 0, n_shaded = 0, n_fetched = 0;
+
+    for (uint32_t si = 0; si < TICKET_SHARDS; ++si) {
+        const uint32_t shard = (shard0 + si) % TICKET_SHARDS;
+        const uint32_t t_begin = shard * per_shard;
+        const uint32_t t_count = t_begin >= n_tasks ? 0u : min(per_shard, n_tasks - t_begin);
+        uint32_t* ticket = w.ticket + shard * TICKET_STRIDE;
+        for (;;) {
+            uint32_t u = 0;
+            if (lane == 0) u = atomicAdd(ticket, 1u);
+            u = __builtin_amdgcn_readfirstlane(u);
+            if (u >= t_count) break;
+            const uint32_t task = t_begin + u;
+            const uint32_t ty = task / tiles_x, tx = task - ty * tiles_x;
+            const uint32_t px = (tx << tw2) + (ray & ((1u << tw2) - 1u));
+            const uint32_t r = (ty << th2) + (ray >> tw2);
+            const bool act = px < wv && r < w.n_rows;
+            uint32_t x = 0, y = 0;
+            v3 orig = cam, dir = V3(0.f, 0.f, 1.f);
+            float tNear = 0.f, tFar = -1.f;
+            bool done = true;
+            if (act) {
+                x = w.x0 + px; y = owned_row_to_y(w, r);
+                camera_ray_pinhole(s, x, y, orig, dir);
+                done = !volume_intersect(s, orig, dir, tNear, tFar);
+            }
+            float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
+            uint32_t steps = 0;
+            // parameter of this lane's sample in the current chunk: t_n, n = chunk * S + j
             float t = tNear;
+#pragma unroll
+            for (uint32_t i = 0; i + 1u < S; ++i) t = (i < j) ? t + h : t;
+            uint32_t gv = 0, gc = 0;             // valid / contributing lanes of this ray's current chunk
+            v3 p = orig;
+            int e = 0;
+            float a = 0.f, alpha = 0.f;
+
             for (;;) {
-                // advance to the next sample that can contribute: opacity > 0 (or a non-finite head-light
-                // direction, which the reference turns into NaNs)
-                bool live = false;
-                v3 p;
-                float co[4];
-                while (t <= tFar) {
-                    steps++;
-                    p = orig + dir * t;
-                    Cell c = cell_of(s, p);
-                    v3 toCam = cam - p;
-                    bool finite = dot(toCam, toCam) >= 1e-30f;
-                    if (SKIP && finite && cell_is_empty<false>(L, s, c)) { t += h; continue; }
-                    fetched++;
-                    float intensity = tex_fetch<LAYOUT>(s, c) * s.densityScale;
-                    int e; float a;
-                    lds_tf_coord(s, intensity, e, a);
+                // ---- advance: rays with nothing pending evaluate chunks until one contributes ----
+                for (;;) {
+                    const bool need = !done && gc == 0u;
+                    if (__ballot(need) == 0ull) break;
+                    const bool valid = need && t <= tFar;
+                    bool contrib = false;
+                    if (valid) {
+                        v3 q = orig + dir * t;
+                        Cell c = cell_of(s, q);
+                        v3 toCam = cam - q;
+                        // the head-light direction must stay finite for "opacity 0 => contributes +0"
+                        const bool finite = dot(toCam, toCam) >= 1e-30f;
+                        if (!(SKIP && finite && cell_is_empty<false>(L, s, c))) {
+                            if (COUNT) n_fetched++;
+                            float intensity = tex_fetch<LAYOUT>(s, c) * s.densityScale;
+                            int ee; float aa;
+                            lds_tf_coord(s, intensity, ee, aa);
+                            float al = lerpf(L.rgba[ee].w, L.rgba[ee + 1].w, aa);
+                            if (!(SKIP && finite && al == 0.f)) {
+                                contrib = true;
+                                p = q; e = ee; a = aa; alpha = al;
+                            }
+                        }
+                    }
+                    const uint64_t vb = __ballot(valid), cb = __ballot(contrib);
+                    if (need) {
+                        gv = (uint32_t)(vb >> gshift) & GMASK;
+                        gc = (uint32_t)(cb >> gshift) & GMASK;
+                        if (gc == 0u) {
+                            const uint32_t nv = (uint32_t)__builtin_popcount(gv);
+                            steps += nv;
+                            if (nv < S) done = true;
+#pragma unroll
+                            for (uint32_t i = 0; i < S; ++i) t += h;
+                        }
+                    }
+                }
+                if (__ballot(!done) == 0ull) break;
+
+                // ---- shade the pending contributing samples ----
+                float co[4] = {0.f, 0.f, 0.f, 0.f};
+                if (!done && ((gc >> j) & 1u)) {
+                    if (COUNT) n_shaded++;
                     float4 t0 = L.rgba[e], t1 = L.rgba[e + 1];
-                    co[3] = lerpf(t0.w, t1.w, a);
-                    if (SKIP && finite && co[3] == 0.f) { t += h; continue; }
                     co[0] = lerpf(t0.x, t1.x, a); co[1] = lerpf(t0.y, t1.y, a); co[2] = lerpf(t0.z, t1.z, a);
-                    live = true;
-                    break;
+                    co[3] = alpha;
+                    // cudaVolume::Gradient_CentralDiff, core/cuda_volume.h:54-61
+                    float xd = intensity_at<LAYOUT>(s, V3(p.x + s.spacing[0], p.y + 0.f, p.z + 0.f)) -
+                               intensity_at<LAYOUT>(s, V3(p.x - s.spacing[0], p.y - 0.f, p.z - 0.f));
+                    float yd = intensity_at<LAYOUT>(s, V3(p.x + 0.f, p.y + s.spacing[1], p.z + 0.f)) -
+                               intensity_at<LAYOUT>(s, V3(p.x - 0.f, p.y - s.spacing[1], p.z - 0.f));
+                    float zd = intensity_at<LAYOUT>(s, V3(p.x + 0.f, p.y + 0.f, p.z + s.spacing[2])) -
+                               intensity_at<LAYOUT>(s, V3(p.x - 0.f, p.y - 0.f, p.z - s.spacing[2]));
+                    v3 gradient = V3((xd * 0.5f) * s.invSpacing[0], (yd * 0.5f) * s.invSpacing[1], (zd * 0.5f) * s.invSpacing[2]);
+                    float gm = __builtin_sqrtf(dot(gradient, gradient));
+                    float cosTerm = 1.f, specularTerm = 0.f;
+                    if ((double)gm > 1e-3) {
+                        v3 normal = normalize(gradient);
+                        v3 lightDir = normalize(cam - p);
+                        cosTerm = __builtin_fabsf(dot(normal, lightDir));
+                        specularTerm = powf_(cosTerm, 30.f);
+                    }
+                    co[0] = co[0] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
+                    co[1] = co[1] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
+                    co[2] = co[2] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
                 }
-                if (!live) break;
-                shaded++;
-                // cudaVolume::Gradient_CentralDiff, core/cuda_volume.h:54-61
-                float xd = intensity_at<LAYOUT>(s, V3(p.x + s.spacing[0], p.y + 0.f, p.z + 0.f)) -
-                           intensity_at<LAYOUT>(s, V3(p.x - s.spacing[0], p.y - 0.f, p.z - 0.f));
-                float yd = intensity_at<LAYOUT>(s, V3(p.x + 0.f, p.y + s.spacing[1], p.z + 0.f)) -
-                           intensity_at<LAYOUT>(s, V3(p.x - 0.f, p.y - s.spacing[1], p.z - 0.f));
-                float zd = intensity_at<LAYOUT>(s, V3(p.x + 0.f, p.y + 0.f, p.z + s.spacing[2])) -
-                           intensity_at<LAYOUT>(s, V3(p.x - 0.f, p.y - 0.f, p.z - s.spacing[2]));
-                v3 gradient = V3((xd * 0.5f) * s.invSpacing[0], (yd * 0.5f) * s.invSpacing[1], (zd * 0.5f) * s.invSpacing[2]);
-                float gm = __builtin_sqrtf(dot(gradient, gradient));
-                float cosTerm = 1.f, specularTerm = 0.f;
-                if ((double)gm > 1e-3) {
-                    v3 normal = normalize(gradient);
-                    v3 lightDir = normalize(cam - p);
-                    cosTerm = __builtin_fabsf(dot(normal, lightDir));
-                    specularTerm = powf_(cosTerm, 30.f);
+
+                // ---- composite the chunk in sample order (every lane of the ray keeps the same L) ----
+#pragma unroll
+                for (uint32_t jj = 0; jj < S; ++jj) {
+                    const int src = (int)(gshift + jj);
+                    float c0 = __shfl(co[0], src, 64), c1 = __shfl(co[1], src, 64);
+                    float c2 = __shfl(co[2], src, 64), c3 = __shfl(co[3], src, 64);
+                    if (!done && ((gc >> jj) & 1u)) {
+                        float wgt = 1.f - La;
+                        Lr += wgt * c0; Lg += wgt * c1; Lb += wgt * c2; La += wgt * c3;
+                        if (La > 0.95f) { done = true; steps += jj + 1u; }
+                    }
                 }
-                co[0] = co[0] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
-                co[1] = co[1] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
-                co[2] = co[2] * co[3] * cosTerm * 0.8f + co[3] * specularTerm * 0.2f;
-                float wgt = 1.f - La;
-                Lr += wgt * co[0]; Lg += wgt * co[1]; Lb += wgt * co[2]; La += wgt * co[3];
-                if (La > 0.95f) break;
-                t += h;
+                if (!done) {
+                    const uint32_t nv = (uint32_t)__builtin_popcount(gv);
+                    steps += nv;
+                    if (nv < S) done = true;
+#pragma unroll
+                    for (uint32_t i = 0; i < S; ++i) t += h;
+                }
+                gc = 0u;
+            }
+
+            if (act && j == 0u) {
+                float cr = fmin_(Lr, 1.f), cg = fmin_(Lg, 1.f), cb = fmin_(Lb, 1.f);
+                uint32_t rgba = to_u8(cr * 255) | (to_u8(cg * 255) << 8) | (to_u8(cb * 255) << 16) | (to_u8(255 * La) << 24);
+                reinterpret_cast<uint32_t*>(w.img)[(size_t)y * s.imageW + x] = rgba;
+                if (COUNT) n_steps += steps;
             }
         }
-        Lr = fmin_(Lr, 1.f); Lg = fmin_(Lg, 1.f); Lb = fmin_(Lb, 1.f);
-        uint32_t rgba = to_u8(Lr * 255) | (to_u8(Lg * 255) << 8) | (to_u8(Lb * 255) << 16) | (to_u8(255 * La) << 24);
-        reinterpret_cast<uint32_t*>(w.img)[(size_t)y * s.imageW + x] = rgba;
     }
     if (COUNT) {
-        unsigned long long st = wave_sum(steps), ex = wave_sum((unsigned long long)fetched + 6ull * shaded);
+        unsigned long long st = wave_sum((unsigned long long)n_steps);
+        unsigned long long ex = wave_sum((unsigned long long)n_fetched + 6ull * n_shaded);
         if (lane == 0) {
             atomicAdd(&w.counters[CNT_RAYCAST], st);
             atomicAdd(&w.counters[CNT_VOL_TAPS], st * 7ull);
@@ -116,26 +206,42 @@ __global__ __launch_bounds__(256) void k_raycast(const DevScene s, const DevWork
     }
 }
 
-template <int LAYOUT>
-static void launch_t(const DevScene& s, const DevWork& w, float stepSize, bool count, uint32_t blocks, hipStream_t st)
+template <int LAYOUT, bool COUNT, bool SKIP>
+static void launch_s(const DevScene& s, const DevWork& w, float stepSize, int sl2, uint32_t max_blocks, hipStream_t st)
 {
-    const bool skip = s.empty_mask != nullptr;
-    if (count) {
-        if (skip) hipLaunchKernelGGL((k_raycast<LAYOUT, true, true>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
-        else hipLaunchKernelGGL((k_raycast<LAYOUT, true, false>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
-    } else {
-        if (skip) hipLaunchKernelGGL((k_raycast<LAYOUT, false, true>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
-        else hipLaunchKernelGGL((k_raycast<LAYOUT, false, false>), dim3(blocks), dim3(256), 0, st, s, w, stepSize);
+    const uint32_t wv = w.x1 - w.x0;
+    auto go = [&](auto tag) {
+        constexpr int SL2 = decltype(tag)::value;
+        constexpr uint32_t P2 = 6u - SL2, tw2 = P2 < 3u ? P2 : 3u, th2 = P2 - tw2;
+        uint32_t n_tasks = ((wv + (1u << tw2) - 1u) >> tw2) * ((w.n_rows + (1u << th2) - 1u) >> th2);
+        uint32_t need = (n_tasks + SVR_RC_THREADS / 64 - 1u) / (SVR_RC_THREADS / 64);
+        uint32_t blocks = need < max_blocks ? need : max_blocks;
+        hipLaunchKernelGGL((k_raycast<LAYOUT, COUNT, SKIP, SL2>), dim3(blocks ? blocks : 1u), dim3(SVR_RC_THREADS), 0, st, s, w, stepSize);
+    };
+    switch (sl2) {
+    case 0: go(std::integral_constant<int, 0>{}); break;
+    case 1: go(std::integral_constant<int, 1>{}); break;
+    case 2: go(std::integral_constant<int, 2>{}); break;
+    case 4: go(std::integral_constant<int, 4>{}); break;
+    case 5: go(std::integral_constant<int, 5>{}); break;
+    default: go(std::integral_constant<int, 3>{}); break;
     }
 }
 
-hipError_t launch_raycast(const DevScene& s, const DevWork& w, float stepSize, bool count, hipStream_t st)
+hipError_t launch_raycast(const DevScene& s, const DevWork& w, float stepSize, bool count, int num_cus, int lanes_log2, hipStream_t st)
 {
-    uint32_t wv = w.x1 - w.x0;
-    if (wv == 0 || w.n_rows == 0) return hipSuccess;
-    uint32_t blocks = ((wv + 15u) >> 4) * ((w.n_rows + 15u) >> 4);
-    if (s.layout == LAYOUT_LINEAR) launch_t<LAYOUT_LINEAR>(s, w, stepSize, count, blocks, st);
-    else launch_t<LAYOUT_BRICK>(s, w, stepSize, count, blocks, st);
+    if (w.x1 == w.x0 || w.n_rows == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(w.ticket, 0, sizeof(uint32_t) * TICKET_SHARDS * TICKET_STRIDE, st);
+    if (e != hipSuccess) return e;
+    const uint32_t max_blocks = (uint32_t)num_cus * 2u;                  // 2 x 8 waves per CU (48 KB LDS each)
+    const bool skip = s.empty_mask != nullptr;
+    if (s.layout == LAYOUT_LINEAR) {
+        if (count) { if (skip) launch_s<LAYOUT_LINEAR, true, true>(s, w, stepSize, lanes_log2, max_blocks, st); else launch_s<LAYOUT_LINEAR, true, false>(s, w, stepSize, lanes_log2, max_blocks, st); }
+        else { if (skip) launch_s<LAYOUT_LINEAR, false, true>(s, w, stepSize, lanes_log2, max_blocks, st); else launch_s<LAYOUT_LINEAR, false, false>(s, w, stepSize, lanes_log2, max_blocks, st); }
+    } else {
+        if (count) { if (skip) launch_s<LAYOUT_BRICK, true, true>(s, w, stepSize, lanes_log2, max_blocks, st); else launch_s<LAYOUT_BRICK, true, false>(s, w, stepSize, lanes_log2, max_blocks, st); }
+        else { if (skip) launch_s<LAYOUT_BRICK, false, true>(s, w, stepSize, lanes_log2, max_blocks, st); else launch_s<LAYOUT_BRICK, false, false>(s, w, stepSize, lanes_log2, max_blocks, st); }
+    }
     return hipGetLastError();
 }
 

@@ -297,4 +297,28 @@ def test_raycasting_cases(hip_dev, case, layout, skip):
     if skip:
         assert cnt["vol_taps_executed"] < cnt["vol_taps"]
     else:
-        assert cnt["vol_taps_executed"] == cnt["vol_taps"]
+        assert cnt["vol_taps_executed"] >= cnt["vol_taps"]      # plus samples evaluated past the early exit
+
+
+@pytest.mark.parametrize("lanes_log2", [0, 1, 2, 4, 5])
+def test_raycasting_lanes_per_ray(hip_dev, lanes_log2):
+    """Any number of lanes per ray (samples of a chunk evaluated in parallel, composited in order) gives the
+    reference's image and step count; 3 (the default) is covered by the tests above."""
+    for sc in (_odd_scene(), scenes.make_scene("tiny_head")):
+        ref, rc = binding.OracleScene(sc).render_raycasting()
+        canvas = host.Canvas(hip_dev, sc.width, sc.height)
+        try:
+            scenes.apply_to_canvas(sc, canvas)
+            canvas.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING)
+            hip_dev.set_option(abi.OPT_RAYCAST_LANES_LOG2, lanes_log2)
+            hip_dev.set_option(abi.OPT_COUNT, 1)
+            hip_dev.reset_counters()
+            canvas.paint(sync=True)
+            img = canvas.read_img()
+            cnt = hip_dev.counters()
+        finally:
+            hip_dev.set_option(abi.OPT_COUNT, 0)
+            hip_dev.set_option(abi.OPT_RAYCAST_LANES_LOG2, 3)
+            canvas.close()
+        assert np.array_equal(img, ref)
+        assert cnt["raycast_steps"] == rc["raycast_steps"]

@@ -10,6 +10,8 @@ dev = host.Device(0)
 c = host.Canvas(dev, sc.width, sc.height)
 scenes.apply_to_canvas(sc, c, 0)
 c.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING)
+import os
+if "RCL" in os.environ: dev.set_option(abi.OPT_RAYCAST_LANES_LOG2, int(os.environ["RCL"]))
 c.paint(sync=True)
 t0 = time.perf_counter(); n = 5
 for _ in range(n):
