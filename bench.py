@@ -218,9 +218,11 @@ def main():
             agg = bytes_per_launch * n_launch / elapsed / 1e9
             roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5),
                          "achieved_aggregate": round(agg, 2), "frac_aggregate": round(agg / HBM_PEAK_GBS, 5),
-                         "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of one launch; "
-                                 "launches of consecutive steps overlap on internal streams, so the aggregate "
-                                 "(all launches' bytes / timed region) is higher",
+                         "note": "achieved = algorithmic bytes of the reference algorithm per launch (16 B per volume "
+                                 "tap it would fetch + 24 B HDR per pixel-frame) / mean HIP-event duration of one launch. "
+                                 "The kernel does not fetch the taps of provably transparent macro-cells (bit-exact "
+                                 "empty-space skipping), so frac can exceed 1: `traffic` is what HBM really moved. The "
+                                 "kernel is VALU-issue bound (profiles/r01_bench_default_prof_summary.txt), not HBM bound",
                          "executed_taps_per_path": round(loc["vol_taps_executed"] / max(1, loc["paths"]), 3),
                          "kernel": {0: "k_trace_tile", 1: "k_pathtrace_pixel", 2: "k_trace_tile", 3: "k_pathtrace_uloop"}[args.kernel],
                          "kernel_avg_ms": round(avg_ms, 4), "kernel_launches": k_n,

@@ -76,6 +76,7 @@ struct Context {
     // device scratch
     unsigned long long* d_counters = nullptr;
     uint32_t* d_ticket = nullptr;
+    hipEvent_t prev_traced = nullptr;   // `traced` event of the latest trace launch (owned by its set)
     // Frame pipelining: a render call is cut into groups of <= GROUP frames; each group is traced on
     // one of NSETS internal streams into that set's scratch slots and resolved (running mean + tone map)
     // on the caller's stream, so the trace kernels of consecutive frames/calls overlap on the GPU while
@@ -83,7 +84,7 @@ struct Context {
 #ifndef SVR_GROUP
 #define SVR_GROUP 32     // frames per trace launch: 8 / 16 / 32 / 64 measured 0.185 / 0.178 / 0.166 / 0.161 ms per frame on c3
 #endif
-    static constexpr int NSETS = 4, GROUP = SVR_GROUP;
+    static constexpr int NSETS = 4, GROUP = SVR_GROUP, CHAIN_MIN_FRAMES = 8;
     struct SlotSet {
         float* lbuf = nullptr;
         hipStream_t stream = nullptr;
@@ -463,6 +464,11 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         w.nframes = n;
         // the scratch slots of this set are free again once their previous resolve has run
         if (g.opt_pipeline && set.used) HIP_TRY(hipStreamWaitEvent(ts, set.resolved, 0));
+        // A many-frame trace launch fills the chip by itself; running two of them at once only makes them share
+        // L2 and stretches both.  They are chained (the resolve of one still overlaps the trace of the next);
+        // few-frame launches (interactive use, one frame per call) overlap freely to hide each other's tails.
+        if (g.opt_pipeline && n >= (uint32_t)Context::CHAIN_MIN_FRAMES && g.prev_traced)
+            HIP_TRY(hipStreamWaitEvent(ts, g.prev_traced, 0));
         int slot = -1;
         if (g.opt_timing) {
             if (g.ev_count == Context::EV_RING) collect_timing();
@@ -480,6 +486,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         }
         if (g.opt_pipeline) {
             HIP_TRY(hipEventRecord(set.traced, ts));
+            g.prev_traced = set.traced;
             HIP_TRY(hipStreamWaitEvent(g.stream, set.traced, 0));
         }
         HIP_TRY(svr::launch_resolve(s, w, g.stream));
