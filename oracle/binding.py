@@ -51,10 +51,116 @@ def _scene_struct(abi):
 _lib = None
 
 
+REFERENCE = Path("/root/reference")
+STB_REF = ORACLE_DIR / "_ref" / "libstb_ref.so"
+
+
 def build(force: bool = False) -> Path:
-    if force or not LIB.exists() or LIB.stat().st_mtime < (ORACLE_DIR / "svr_oracle.c").stat().st_mtime:
+    srcs = [ORACLE_DIR / f for f in ("svr_oracle.c", "svr_oracle.h", "svr_io_oracle.c", "svr_io_oracle.h")]
+    if force or not LIB.exists() or any(LIB.stat().st_mtime < f.stat().st_mtime for f in srcs):
         subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "libsvr_oracle.so"], check=True, capture_output=True)
+    build_ref(force)
     return LIB
+
+
+def build_ref(force: bool = False):
+    """oracle/_ref/libstb_ref.so: the reference's vendored stb headers compiled where they lie.  Only possible
+    where /root/reference exists (this container); the GPU box uses the prebuilt file."""
+    if (REFERENCE / "utils" / "stb_image.h").exists() and (force or not STB_REF.exists()
+                                                         or STB_REF.stat().st_mtime < (ORACLE_DIR / "stb_ref.c").stat().st_mtime):
+        subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "_ref/libstb_ref.so"], check=True, capture_output=True)
+    return STB_REF if STB_REF.exists() else None
+
+
+_stb = None
+
+
+def stb_ref():
+    """The reference's own stb_image / stb_image_write (None if oracle/_ref was not built and cannot be)."""
+    global _stb
+    if _stb is None:
+        path = build_ref()
+        if path is None:
+            return None
+        lib = C.CDLL(str(path))
+        lib.stbi_loadf.restype = C.POINTER(C.c_float)
+        lib.stbi_loadf.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+        lib.stbi_image_free.restype, lib.stbi_image_free.argtypes = None, [C.c_void_p]
+        lib.stbi_write_tga.restype = C.c_int
+        lib.stbi_write_tga.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.stbi_write_hdr.restype = C.c_int
+        lib.stbi_write_hdr.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _stb = lib
+    return _stb
+
+
+def ref_loadf(path: str):
+    """stbi_loadf(path, &w, &h, &n, 0) of the reference's stb_image.h -> ([h][w][n] float32) or None."""
+    lib = stb_ref()
+    w, h, n = C.c_int(0), C.c_int(0), C.c_int(0)
+    p = lib.stbi_loadf(str(path).encode(), C.byref(w), C.byref(h), C.byref(n), 0)
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(p, shape=(h.value, w.value, n.value)).copy()
+    lib.stbi_image_free(p)
+    return out
+
+
+def ref_write_tga(path: str, img: np.ndarray) -> bytes:
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    ok = stb_ref().stbi_write_tga(str(path).encode(), a.shape[1], a.shape[0], a.shape[2], a.ctypes.data_as(C.c_void_p))
+    assert ok
+    return Path(path).read_bytes()
+
+
+def ref_write_hdr(path: str, img: np.ndarray):
+    a = np.ascontiguousarray(img, dtype=np.float32)
+    ok = stb_ref().stbi_write_hdr(str(path).encode(), a.shape[1], a.shape[0], a.shape[2], a.ctypes.data_as(C.c_void_p))
+    assert ok
+
+
+# ---- svr_io_oracle.c -------------------------------------------------------------------------------
+_ELEM_DTYPES = [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.float32, np.float64]
+
+
+def elem_type_of(dtype) -> int:
+    return [np.dtype(d) for d in _ELEM_DTYPES].index(np.dtype(dtype))
+
+
+def io_preprocess(elems: np.ndarray, spacing, hist_capacity: int = 65536) -> dict:
+    """VolumeReader::Read after the file is in memory (VolumeReader.cpp:41-76), step by step on the CPU."""
+    lib = load()
+    a = np.ascontiguousarray(elems)
+    nz, ny, nx = a.shape
+    n = a.size
+    shorts = np.zeros(n, dtype=np.int16)
+    lib.svo_cast_to_short(a.ctypes.data_as(C.c_void_p), elem_type_of(a.dtype), C.c_size_t(n), shorts.ctypes.data_as(C.c_void_p))
+    rng = (C.c_double * 2)()
+    lib.svo_scalar_range(shorts.ctypes.data_as(C.c_void_p), C.c_size_t(n), rng)
+    u16 = np.zeros(n, dtype=np.uint16)
+    lib.svo_rescale(shorts.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.c_float(rng[0]), C.c_float(rng[1]), u16.ctypes.data_as(C.c_void_p))
+    hist = np.zeros(hist_capacity, dtype=np.uint32)
+    bins = lib.svo_histogram(shorts.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.c_double(rng[0]), C.c_double(rng[1]),
+                             hist.ctypes.data_as(C.c_void_p), hist_capacity)
+    sp = (C.c_double * 3)(*[float(s) for s in spacing])
+    mm = lib.svo_max_gradient_magnitude(shorts.ctypes.data_as(C.c_void_p), nx, ny, nz, sp)
+    return {"shorts": shorts.reshape(a.shape), "range": (float(rng[0]), float(rng[1])), "u16": u16.reshape(a.shape),
+            "hist": hist[: min(bins, hist_capacity)].copy(), "hist_bins": int(bins), "maxMagnitude": float(mm)}
+
+
+def io_tf_table(opacity_nodes, color_nodes, size: int = 1024):
+    """TransferFunction ctor (transferfunction.cpp:17-28): (table [size][4] float32, maxOpacity)."""
+    lib = load()
+    o = np.ascontiguousarray(np.array(opacity_nodes, dtype=np.float64).reshape(-1, 4))
+    c = np.ascontiguousarray(np.array(color_nodes, dtype=np.float64).reshape(-1, 6))
+    ot, ct = np.zeros(size, dtype=np.float32), np.zeros((size, 3), dtype=np.float32)
+    lib.svo_piecewise_table(o.ctypes.data_as(C.c_void_p), o.shape[0], 1, size, ot.ctypes.data_as(C.c_void_p))
+    lib.svo_color_table(c.ctypes.data_as(C.c_void_p), c.shape[0], 1, size, ct.ctypes.data_as(C.c_void_p))
+    table = np.concatenate([ct, ot[:, None]], axis=1).astype(np.float32)
+    mo = np.float32(0)
+    for v in ot:
+        mo = np.float32(max(mo, v))
+    return table, float(mo)
 
 
 def load():
@@ -99,6 +205,14 @@ def load():
     lib.svo_render_raycasting.argtypes = [C.c_void_p, C.c_void_p, F, I, I, I, I, C.c_void_p, I]
     lib.svo_max_threads.restype, lib.svo_max_threads.argtypes = I, []
     lib.svo_sizeof.restype, lib.svo_sizeof.argtypes = I, [I]
+    VP, SZ, D = C.c_void_p, C.c_size_t, C.c_double
+    lib.svo_cast_to_short.restype, lib.svo_cast_to_short.argtypes = None, [VP, I, SZ, VP]
+    lib.svo_scalar_range.restype, lib.svo_scalar_range.argtypes = None, [VP, SZ, C.POINTER(D)]
+    lib.svo_rescale.restype, lib.svo_rescale.argtypes = None, [VP, SZ, F, F, VP]
+    lib.svo_histogram.restype, lib.svo_histogram.argtypes = I, [VP, SZ, D, D, VP, I]
+    lib.svo_max_gradient_magnitude.restype, lib.svo_max_gradient_magnitude.argtypes = F, [VP, I, I, I, C.POINTER(D)]
+    lib.svo_piecewise_table.restype, lib.svo_piecewise_table.argtypes = None, [VP, I, I, I, VP]
+    lib.svo_color_table.restype, lib.svo_color_table.argtypes = None, [VP, I, I, I, VP]
     _lib = lib
     return lib
 

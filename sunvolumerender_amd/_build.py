@@ -17,7 +17,7 @@ CSRC = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
 LIB_PATH = Path(os.environ["SVR_HIP_LIB"]) if os.environ.get("SVR_HIP_LIB") else LIB_DIR / "libsvr_hip.so"
 
-HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_wavefront.hip", "svr_accel.hip", "svr_raycast.hip"]
+HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_wavefront.hip", "svr_accel.hip", "svr_raycast.hip", "svr_host_io.hip", "svr_volume_prep.hip"]
 HIP_HEADERS = ["svr_math.hpp", "svr_scene.hpp", "svr_device.hpp", "svr_kernels.hpp", "svr_kernel_common.hpp", "svr_walk.hpp"]
 
 HIPCC_FLAGS = [
@@ -25,13 +25,14 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-std=c++17",
     "-fPIC",
-    "-shared",
     "-ffp-contract=off",
     "-fno-fast-math",
     "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall",
     "-Wno-unused-value",
+    "-I" + str(REPO_ROOT / "include"),
 ]
+LINK_LIBS = ["-lz"]          # MetaImage CompressedData (svr_host_io.hip)
 
 
 def _hipcc() -> str:
@@ -49,17 +50,39 @@ def _stale(target: Path, deps) -> bool:
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the HIP kernels + C-ABI into sunvolumerender_amd/lib/libsvr_hip.so."""
+    """Compile the HIP kernels + C-ABI into sunvolumerender_amd/lib/libsvr_hip.so: one object per source
+    (compiled in parallel, only when stale), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
     LIB_DIR.mkdir(exist_ok=True)
-    deps = [CSRC / f for f in HIP_SOURCES + HIP_HEADERS] + [REPO_ROOT / "include" / "svr_abi.h", Path(__file__)]
-    if not force and not _stale(LIB_PATH, deps):
-        return LIB_PATH
-    cmd = [_hipcc(), *HIPCC_FLAGS, *[str(CSRC / f) for f in HIP_SOURCES], "-o", str(LIB_PATH)]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    obj_dir = LIB_DIR / "obj"
+    obj_dir.mkdir(exist_ok=True)
+    common = [CSRC / f for f in HIP_HEADERS] + [REPO_ROOT / "include" / "svr_abi.h", REPO_ROOT / "include" / "svr_io.h",
+                                                CSRC / "svr_internal.hpp", Path(__file__)]
+    hipcc = _hipcc()
+
+    def compile_one(name: str):
+        src, obj = CSRC / name, obj_dir / (Path(name).stem + ".o")
+        if not force and not _stale(obj, [src, *common]):
+            return obj, False
+        cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {name} ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+        return obj, True
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_one, HIP_SOURCES))
+    objs = [o for o, _ in results]
+    if force or any(changed for _, changed in results) or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(o) for o in objs], *LINK_LIBS, "-o", str(LIB_PATH)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
     return LIB_PATH
 
 

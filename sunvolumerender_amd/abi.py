@@ -136,7 +136,26 @@ OPT_PIPELINE, OPT_REFILL_MIN_IDLE, OPT_EMPTY_SKIP, OPT_RAY_SKIP, OPT_FRAMES_PER_
 OPT_RAYCAST_LANES_LOG2 = 12
 KERNEL_AUTO, KERNEL_PIXEL, KERNEL_TILE, KERNEL_ULOOP, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4
 
-# every symbol include/svr_abi.h declares: name -> (restype, argtypes)
+ELEM_I8, ELEM_U8, ELEM_I16, ELEM_U16, ELEM_I32, ELEM_U32, ELEM_F32, ELEM_F64 = range(8)
+
+
+class MhdHeader(C.Structure):          # svr_mhd_header, include/svr_io.h
+    _fields_ = [
+        ("ndims", C.c_int32), ("dim", C.c_int32 * 3), ("spacing", C.c_double * 3),
+        ("elem_type", C.c_int32), ("elem_size", C.c_int32), ("channels", C.c_int32), ("msb", C.c_int32),
+        ("compressed", C.c_int32), ("compressed_size", C.c_int64), ("header_size", C.c_int64),
+        ("data_offset", C.c_int64), ("data_file", C.c_char * 1024),
+    ]
+
+
+class VolumeInfo(C.Structure):         # svr_volume_info, include/svr_io.h
+    _fields_ = [
+        ("dim", C.c_int32 * 3), ("spacing", C.c_float * 3), ("range", C.c_double * 2),
+        ("maxMagnitude", C.c_float), ("hist_bins", C.c_uint32),
+    ]
+
+
+# every symbol include/svr_abi.h and include/svr_io.h declare: name -> (restype, argtypes)
 _P = C.POINTER
 PROTOTYPES = {
     # (A) the reference's entry points
@@ -180,6 +199,20 @@ PROTOTYPES = {
     "svr_reset_kernel_time": (C.c_int, []),
     "svr_device_info": (C.c_char_p, []),
     "svr_abi_version": (C.c_int, []),
+    # include/svr_io.h: the host-side rows N1-N4
+    "svr_mhd_read_header": (C.c_int, [C.c_char_p, _P(MhdHeader)]),
+    "svr_mhd_read_elements": (C.c_int, [_P(MhdHeader), C.c_void_p, C.c_size_t]),
+    "svr_volume_preprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _P(C.c_double), C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_uint32, _P(VolumeInfo)]),
+    "svr_load_mhd": (C.c_int, [C.c_char_p, C.c_int, _P(cudaVolume), _P(VolumeInfo), C.c_void_p, C.c_uint32]),
+    "svr_volume_preprocess_last_ms": (C.c_int, [_P(C.c_float), _P(C.c_uint64)]),
+    "svr_tf_build_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, _P(C.c_float)]),
+    "svr_tf_save": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "svr_tf_load": (C.c_int, [C.c_char_p, C.c_void_p, _P(C.c_int), C.c_void_p, _P(C.c_int)]),
+    "svr_hdr_load": (C.c_int, [C.c_char_p, _P(C.c_int), _P(C.c_int), C.c_void_p, C.c_size_t]),
+    "svr_load_env_map": (C.c_int, [C.c_char_p, _P(cudaEnvironmentLight)]),
+    "svr_tga_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
+    "svr_tga_encode": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
 }
 
 _lib = None

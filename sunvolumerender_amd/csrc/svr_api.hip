@@ -498,6 +498,13 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
 
 } // namespace
 
+// hooks for the other translation units of the library (svr_internal.hpp)
+namespace svr {
+int report_error(int code, const char* msg) { return fail(code, "%s", msg); }
+int ensure_ready() { return ensure_init(); }
+hipStream_t current_stream() { return g.stream; }
+}
+
 extern "C" {
 
 int svr_abi_version(void) { return 1; }

@@ -291,6 +291,44 @@ class Canvas:
         self.ready = True
         self.ReStartRender()
 
+    def LoadVolumeFile(self, filename: str, layout: int = abi.LAYOUT_AUTO):
+        """Canvas::LoadVolume(filename), gui/canvas.cpp:27-41, with the reference's reader replaced by
+        io.VolumeReader (MetaImage parse on the host, preprocessing on the GPU)."""
+        from .io import VolumeReader
+        if getattr(self, "volumeReader", None) is not None:
+            self.volumeReader.ClearDevice()
+        self.volumeReader = VolumeReader(self.dev, layout)
+        self.volumeReader.Read(filename)
+        self.volumeReader.CreateDeviceVolume(self.deviceVolume)
+        self.deviceVolume.x_clip, self.deviceVolume.y_clip, self.deviceVolume.z_clip = vec2(-1, 1), vec2(-1, 1), vec2(-1, 1)
+        self.deviceVolume.densityScale = 1.0
+        self.lib.setup_volume(C.byref(self.deviceVolume)); self.dev.check()
+        self.stepSize = self.volumeReader.GetElementBoundingSphereRadius()
+        self.volumeSize = self.volumeReader.GetVolumeSize()
+        self.boundingSphereRadius = self.volumeReader.GetBoundingSphereRadius()
+        self.eyeDist = zoom_to_extent_eye_dist(self.volumeSize, self.fov)
+        self.camera = camera_setup((0.0, 0.0, self.eyeDist), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), self.fov, self.apeture,
+                                   self.focalLength, self.exposure, self.W, self.H)
+        self.lib.setup_camera(C.byref(self.camera)); self.dev.check()
+        self.ready = True
+        self.ReStartRender()
+
+    def SetEnvLightMap(self, filename: str):
+        """gui/canvas.h:104-109: Lights::SetEnvironmentLight(filename) + setup_env_lights."""
+        old = int(self.env.tex)
+        self.dev.check(self.lib.svr_load_env_map(str(filename).encode(), C.byref(self.env)))
+        self._textures.append(int(self.env.tex))
+        if old in self._textures:
+            self._textures.remove(old)
+            self.lib.svr_destroy_texture(old)
+        self.lib.setup_env_lights(C.byref(self.env)); self.dev.check()
+        self.ReStartRender()
+
+    def SaveFrame(self, filename: str = "0.tga"):
+        """The frame dump of gui/canvas.cpp:97-104 (stbi_write_tga of the RGBA8 image)."""
+        from .io import save_tga
+        save_tga(self.dev, filename, self.read_img())
+
     def SetCamera(self, cam: cudaCamera):
         self.camera = cam
         self.lib.setup_camera(C.byref(self.camera)); self.dev.check()
@@ -407,6 +445,9 @@ class Canvas:
         for h in self._textures:
             self.lib.svr_destroy_texture(h)
         self._textures.clear()
+        if getattr(self, "volumeReader", None) is not None:
+            self.volumeReader.ClearDevice()
+            self.volumeReader = None
         if self._own_hdr:
             self.lib.svr_render_params_clear(C.byref(self.renderParams))
         if self._own_img and self.img:
