@@ -1,4 +1,4 @@
-"""The C-ABI library builds, loads, and exports every symbol include/svr_abi.h declares; the POD layouts
+"""The C-ABI library builds, loads, and exports every symbol include/svr_abi.h and include/svr_io.h declare; the POD layouts
 match the reference's classes byte for byte.  No compute calls (no GPU here)."""
 import ctypes as C
 import re
@@ -9,7 +9,7 @@ import pytest
 from sunvolumerender_amd import abi
 
 ROOT = Path(__file__).resolve().parents[1]
-HEADER = (ROOT / "include" / "svr_abi.h").read_text()
+HEADER = (ROOT / "include" / "svr_abi.h").read_text() + "\n" + (ROOT / "include" / "svr_io.h").read_text()
 
 
 def declared_functions():
@@ -25,10 +25,10 @@ def test_library_present_and_exports_every_declared_symbol():
     decl = declared_functions()
     assert len(decl) >= 35
     for name in decl:
-        assert hasattr(lib, name), f"{name} declared in svr_abi.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
         assert name in abi.PROTOTYPES, f"{name} has no ctypes prototype"
     for name in abi.PROTOTYPES:
-        assert name in decl, f"{name} bound in abi.py but not declared in svr_abi.h"
+        assert name in decl, f"{name} bound in abi.py but not declared in include/*.h"
 
 
 def test_reference_entry_points_have_reference_names():
