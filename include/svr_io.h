@@ -9,7 +9,8 @@
  *
  * File parsing is host code; everything proportional to the voxel count (cast, range, rescale, histogram,
  * gradient magnitude, brick repack) runs on the GPU.  All functions return 0 on success, or a negative
- * code with svr_last_error() set (they never exit, unlike the reference's exit(0) on a bad file).
+ * code with svr_last_error() set; under the default error mode (svr_set_error_mode(1)) a failure prints the
+ * message and exits, as the reference does on a bad file (VolumeReader.cpp:20-39, lights.cpp:36-40).
  */
 #ifndef SVR_IO_H
 #define SVR_IO_H
@@ -40,7 +41,7 @@ typedef struct svr_mhd_header {
     int64_t  compressed_size;       /* CompressedDataSize, 0 if absent */
     int64_t  header_size;           /* HeaderSize; -1 = data are the last bytes of the file */
     int64_t  data_offset;           /* ElementDataFile = LOCAL: offset of the first data byte in the header file */
-    char     data_file[1024];       /* resolved path of the element data ("" = LOCAL) */
+    char     data_file[1024];       /* resolved path of the element data (the header file itself for LOCAL; "LIST" for per-slice files) */
 } svr_mhd_header;
 
 /* what VolumeReader keeps after Read() (VolumeReader.h:44-50) */
@@ -95,7 +96,8 @@ int svr_tf_load(const char* path, double* opacity_nodes, int* n_opacity, double*
 /* stbi_loadf(filename, &w, &h, &n, 0) for .hdr files (stb_image.h v2.12, 6072-6239), then the float4
  * expansion of lights.cpp:45-53 (w = 0).  Two-call protocol: with rgba == NULL only *w, *h are returned. */
 int svr_hdr_load(const char* path, int* w, int* h, float* rgba, size_t rgba_floats);
-/* Lights::SetEnvironmentLight(filename): load + svr_create_env_texture + env->tex (lights.cpp:31-75) */
+/* Lights::SetEnvironmentLight(filename): load + svr_create_env_texture + cudaEnvironmentLight::Set(tex), which
+ * also resets intensity to 1 and offset to 0 (lights.cpp:31-75, cuda_environment_light.h:18-23) */
 int svr_load_env_map(const char* path, svr_environment_light* env);
 
 /* ---- N1: frame dump ---------------------------------------------------------------------------- */

@@ -492,7 +492,10 @@ int svr_load_env_map(const char* path, svr_environment_light* env)
     if (rc) return rc;
     uint64_t tex = svr_create_env_texture(rgba.data(), w, h, 0);
     if (!tex) return svr_last_error_code();
-    env->tex = tex;                                        // cudaEnvironmentLight::Set(tex), lights.cpp:74
+    // cudaEnvironmentLight::Set(tex) (lights.cpp:74, cuda_environment_light.h:18-23) also resets intensity and offset
+    env->tex = tex;
+    env->intensity = 1.f;
+    env->offset.x = 0.f; env->offset.y = 0.f;
     return 0;
 }
 

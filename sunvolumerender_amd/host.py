@@ -314,7 +314,8 @@ class Canvas:
         self.ReStartRender()
 
     def SetEnvLightMap(self, filename: str):
-        """gui/canvas.h:104-109: Lights::SetEnvironmentLight(filename) + setup_env_lights."""
+        """gui/canvas.h:104-109: Lights::SetEnvironmentLight(filename) + setup_env_lights.  Like the reference's
+        cudaEnvironmentLight::Set(tex), this resets the intensity to 1 and the offset to 0."""
         old = int(self.env.tex)
         self.dev.check(self.lib.svr_load_env_map(str(filename).encode(), C.byref(self.env)))
         self._textures.append(int(self.env.tex))

@@ -80,16 +80,17 @@ def test_product_does_not_reference_the_oracle():
     assert "oracle" not in out
 
 
-def test_cpp_host_header_compiles_and_links(tmp_path):
-    """include/sunvolumerender/host_api.hpp + examples/headless_canvas.cpp build with plain g++ against the
-    C ABI (compile + link only; running it needs a GPU)."""
+@pytest.mark.parametrize("example", ["headless_canvas", "render_mhd"])
+def test_cpp_host_headers_compile_and_link(tmp_path, example):
+    """include/sunvolumerender/{host_api,canvas}.hpp + the examples build with plain g++ against the C ABI
+    (compile + link only; running them needs a GPU: tests/test_io_gpu.py)."""
     import shutil
     import subprocess
 
     if shutil.which("g++") is None:
         pytest.skip("no g++")
-    exe = tmp_path / "headless_canvas"
-    cmd = ["g++", "-std=c++14", "-O1", "-Wall", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "headless_canvas.cpp"),
+    exe = tmp_path / example
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "examples" / f"{example}.cpp"),
            "-o", str(exe), f"-L{abi.library_path().parent}", "-lsvr_hip"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr

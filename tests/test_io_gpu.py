@@ -189,6 +189,8 @@ def test_env_map_file(hip_dev, tmp_path):
     try:
         scenes.apply_to_canvas(dataclasses.replace(sc, env_map=None), canvas)
         canvas.SetEnvLightMap(str(path))
+        assert canvas.env.intensity == 1.0 and (canvas.env.offset.x, canvas.env.offset.y) == (0.0, 0.0)   # Set(tex) resets both
+        canvas.SetEnvLightIntensity(sc.env_intensity)
         canvas.SetEnvLightOffset(sc.env_offset)
         for f in range(2):
             canvas.paint()
@@ -222,4 +224,69 @@ def test_transfer_function_class(hip_dev, tmp_path):
         ref, ref_mo = binding.io_tf_table(nodes, GUI_COLOR)
         assert np.array_equal(tf.compositeTable, ref) and tf.maxOpacity == ref_mo and 0.89 < ref_mo <= 0.9
     finally:
+        tf.close()
+
+
+def test_cpp_canvas_example_matches_python_canvas(hip_dev, tmp_path):
+    """examples/render_mhd.cpp (C++ Canvas / VolumeReader / TransferFunction / Lights of include/sunvolumerender/canvas.hpp)
+    run as its own process writes the same TGA as the Python Canvas replaying the same protocol, which the oracle
+    confirms."""
+    import shutil
+    import subprocess
+    from tests.test_io_cpu import GUI_COLOR, GUI_OPACITY
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = Path(__file__).resolve().parents[1]
+    exe = tmp_path / "render_mhd"
+    libdir = abi.library_path().parent
+    res = subprocess.run(["g++", "-std=c++14", "-O1", f"-I{root / 'include'}", str(root / "examples" / "render_mhd.cpp"), "-o", str(exe),
+                          f"-L{libdir}", "-lsvr_hip", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    vol = _ct_like()
+    spacing = (0.9, 0.9, 1.5)
+    mhd = write_mhd(tmp_path / "ct.mhd", vol, spacing)
+    rs = np.random.RandomState(8)
+    sky = write_hdr(tmp_path / "sky.hdr", float_to_rgbe((rs.uniform(0, 1, (8, 16, 3)) ** 2 * 5).astype(np.float32)))
+    W, H = 64, 48
+    res = subprocess.run([str(exe), str(mhd), "-env", str(sky), "-frames", "3", "-depth", "2", "-size", str(W), str(H), "-o", str(tmp_path / "cpp.tga")],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    res2 = subprocess.run([str(exe), str(mhd), "-raycast", "-size", str(W), str(H), "-o", str(tmp_path / "cpp_rc.tga")], capture_output=True, text=True, timeout=120)
+    assert res2.returncode == 0, res2.stdout + res2.stderr
+
+    # the same protocol through the Python mirror
+    tf = io.TransferFunction(hip_dev, GUI_OPACITY, GUI_COLOR)
+    canvas = host.Canvas(hip_dev, W, H)
+    try:
+        canvas.SetTransferFunction(tf.Upload(), tf.maxOpacity)
+        canvas.LoadVolumeFile(str(mhd))
+        dist = np.float32(canvas.volumeReader.GetBoundingSphereRadius()) * np.float32(1.5) + np.float32(1.0)
+        light = host.make_area_light((0.0, float(dist), 0.0), (0.0, -1.0, 0.0), 10.0, (1.0, 1.0, 1.0), 500.0)
+        canvas.SetAreaLights([light])
+        canvas.SetEnvLightMap(str(sky))
+        hip_dev.set_option(abi.OPT_ENV_ON_ESCAPE, 1)
+        canvas.SetScatterTimes(2)
+        for f in range(3):
+            canvas.paint()
+        hip_dev.synchronize()
+        img = canvas.read_img()
+        assert (tmp_path / "cpp.tga").read_bytes() == io.tga_encode(hip_dev, img)
+        # and the oracle agrees with both
+        ref = binding.io_preprocess(vol, spacing)
+        sc = scenes.Scene(name="cpp", vox=ref["u16"], spacing=tuple(float(np.float32(s)) for s in spacing), max_magnitude=ref["maxMagnitude"],
+                          tf_rgba=tf.compositeTable, max_opacity=tf.maxOpacity, width=W, height=H, lights=[light], trace_depth=2,
+                          env_map=io.hdr_load(hip_dev, str(sky)), env_on_escape=True, env_intensity=1.0)
+        orc = binding.OracleScene(sc)
+        hdr_ref = np.zeros((H, W, 3), dtype=np.float32)
+        img_ref = np.zeros((H, W, 4), dtype=np.uint8)
+        for f in range(3):
+            orc.render_pathtracer(hdr_ref, f, 2, img=img_ref)
+        assert np.array_equal(img, img_ref)
+        canvas.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING)
+        canvas.paint(sync=True)
+        assert (tmp_path / "cpp_rc.tga").read_bytes() == io.tga_encode(hip_dev, canvas.read_img())
+    finally:
+        hip_dev.set_option(abi.OPT_ENV_ON_ESCAPE, 0)
+        canvas.close()
         tf.close()
