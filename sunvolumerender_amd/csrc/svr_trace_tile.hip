@@ -39,7 +39,7 @@ namespace svr {
 // the next-event estimate, which leaves registers for the re-marching shadow walk.
 template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS>
 SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_t y, uint32_t traceDepth_,
-                           uint32_t hashed, uint32_t debug_stop, Cnt& c)
+                           uint32_t hashed, uint32_t debug_stop, bool group_march, uint32_t P2, Cnt& c)
 {
     const uint32_t traceDepth = DEPTH1 ? 1u : traceDepth_;
     uint32_t offset = y * s.imageW + x;
@@ -59,7 +59,15 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
     }
     for (uint32_t k = 0; k < traceDepth; ++k) {
         float tMin = (float)1e-6, tMax = SVR_FLT_MAX, val = 0.f;
-        float t = walk<LAYOUT, COUNT, SKIP, SVR_PRIMARY_REMARCH>(s, L_, orig, dir, rng, tMin, tMax, val, false, c);
+        float t;
+        if (SKIP && k == 0 && group_march) {
+            // the wave is full and its lanes are pixels x frames: one shared whole-ray test per pixel
+            float t_occ;
+            int r = walk_setup_group<COUNT, SKIP>(s, L_, P2, orig, dir, false, tMin, tMax, t_occ);
+            t = r <= 0 ? -SVR_FLT_MAX
+                       : walk_run<LAYOUT, COUNT, SKIP, SVR_PRIMARY_REMARCH>(s, L_, orig, dir, rng, tMin, tMax, t_occ, val, false, c);
+        } else
+            t = walk<LAYOUT, COUNT, SKIP, SVR_PRIMARY_REMARCH>(s, L_, orig, dir, rng, tMin, tMax, val, false, c);
         if (debug_stop == 3u) return V3(t, val, 0.f);
         if (k == 0 && ls_id >= 0) {
             t = t < 0.f ? SVR_FLT_MAX : t;
@@ -188,9 +196,12 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 uint32_t slot = (fg << fl2) + (lane >> P2);
                 uint32_t px = (tx << tw2) + (pl & ((1u << tw2) - 1u));
                 uint32_t r = (ty << th2) + (pl >> tw2);
-                if (px < wv && r < w.n_rows && slot < w.nframes) {
+                const bool live = px < wv && r < w.n_rows && slot < w.nframes;
+                // shared whole-ray test: >= 8 frames of a pixel in the wave, every lane alive (the group shuffles)
+                const bool group_march = SKIP && fl2 >= 3u && w.debug_stop == 0u && __ballot(live) == ~0ull;
+                if (live) {
                     uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
-                    v3 L = trace_path_tile<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, x, y, w.traceDepth, wang_hash(w.frame0 + slot), w.debug_stop, c);
+                    v3 L = trace_path_tile<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, x, y, w.traceDepth, wang_hash(w.frame0 + slot), w.debug_stop, group_march, P2, c);
                     float* o = w.lbuf + (size_t)slot * w.slot_stride + 3 * ((size_t)y * s.imageW + x);
                     o[0] = L.x; o[1] = L.y; o[2] = L.z;
                 }

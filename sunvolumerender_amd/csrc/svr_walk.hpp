@@ -178,6 +178,60 @@ SVR_DEV float first_occupied(const DevScene& s, const LDS& L, v3 o, v3 d, float 
     return t;   // guard exhausted (cannot happen: each step leaves a cell): treat the rest as occupied
 }
 
+// The same question for a GROUP of lanes at once.  With frame-major lanes (svr_trace_tile.hip) the 1 << fl2 lanes
+// pl, pl + 2^P2, pl + 2 * 2^P2 ... of a wave trace one pixel in different frames: primary rays from one origin whose
+// directions differ by sub-pixel jitter -- a small fraction of a macro-cell over the whole box.  Instead of 2^fl2
+// identical sequential DDAs the group samples its FIRST lane's ray at steps of 0.7 macro-cell (largest axis), one
+// sample per lane and round, and takes the first sample that is not deep-empty.  A lane may use the result if it has
+// the same origin and stays within 0.25 macro-cell of the reference ray up to the far end of the group's segment:
+// every point of its ray before the returned parameter is then within 0.95 cell (per axis) of an earlier, deep-empty
+// sample, i.e. in that cell or one of its 26 neighbours, which are all empty.  Lanes that fail the test (`ok` false:
+// thin lens, wide pixels on a coarse grid) fall back to their own DDA.  Must be called by all 64 lanes of the wave.
+template <typename LDS>
+SVR_DEV float first_occupied_group(const DevScene& s, const LDS& L, uint32_t P2, v3 o, v3 d, bool hit, float tMin, float tMax, bool& ok)
+{
+    const float INF = u2f(SVR_INF_BITS);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pl = lane & ((1u << P2) - 1u), m = lane >> P2, Lg = 64u >> P2;
+    const int leader = (int)pl;
+    const v3 oc = V3(__shfl(o.x, leader, 64), __shfl(o.y, leader, 64), __shfl(o.z, leader, 64));
+    const v3 dc = V3(__shfl(d.x, leader, 64), __shfl(d.y, leader, 64), __shfl(d.z, leader, 64));
+    float lo = hit ? tMin : INF, hi = hit ? tMax : -INF;
+    for (uint32_t off = 32u; off >= (1u << P2); off >>= 1) {
+        lo = fmin_(lo, __shfl_xor(lo, (int)off, 64));
+        hi = fmax_(hi, __shfl_xor(hi, (int)off, 64));
+    }
+    const float dev = fmax_(__builtin_fabsf((d.x - dc.x) * s.mc_scale[0]),
+                            fmax_(__builtin_fabsf((d.y - dc.y) * s.mc_scale[1]), __builtin_fabsf((d.z - dc.z) * s.mc_scale[2])));
+    ok = (o.x == oc.x) && (o.y == oc.y) && (o.z == oc.z) && (dev * hi <= 0.25f);
+    if (!(lo <= hi)) return INF;                                   // no lane of the group hits the box
+    const float Ax = fma_(oc.x - s.vmin[0], s.mc_scale[0], s.mc_off), Bx = dc.x * s.mc_scale[0];
+    const float Ay = fma_(oc.y - s.vmin[1], s.mc_scale[1], s.mc_off), By = dc.y * s.mc_scale[1];
+    const float Az = fma_(oc.z - s.vmin[2], s.mc_scale[2], s.mc_off), Bz = dc.z * s.mc_scale[2];
+    const float bmax = fmax_(__builtin_fabsf(Bx), fmax_(__builtin_fabsf(By), __builtin_fabsf(Bz)));
+    if (!(bmax > 0.f)) { ok = false; return INF; }
+    const float dt = 0.7f / bmax;
+    // bits of this group in a ballot: lanes pl + j * 2^P2
+    const uint64_t every[7] = {~0ull, 0x5555555555555555ull, 0x1111111111111111ull, 0x0101010101010101ull,
+                               0x0001000100010001ull, 0x0000000100000001ull, 1ull};
+    const uint64_t gmask = every[P2] << pl;
+    const int gx = s.mc_gx, gy = s.mc_gy, gz = s.mc_gz;
+    const uint32_t* deep = L.mask;
+    float result = INF;
+    for (uint32_t k0 = 0u; k0 < 4096u; k0 += Lg) {
+        const float tk = fma_((float)(k0 + m), dt, lo);
+        const int ix = min(max((int)__builtin_floorf(fma_(Bx, tk, Ax)), 0), gx - 1);
+        const int iy = min(max((int)__builtin_floorf(fma_(By, tk, Ay)), 0), gy - 1);
+        const int iz = min(max((int)__builtin_floorf(fma_(Bz, tk, Az)), 0), gz - 1);
+        const uint32_t q = (uint32_t)(ix + iy * gx + iz * s.mc_gxy);
+        const bool occupied = (tk <= hi) && !((deep[q >> 5] >> (q & 31u)) & 1u);
+        const uint64_t b = __ballot(occupied) & gmask;
+        if (b) { result = fma_((float)(k0 + (((uint32_t)__builtin_ctzll(b) - pl) >> P2)), dt, lo); break; }
+        if (fma_((float)(k0 + Lg - 1u), dt, lo) > hi) break;        // the round reached the end of the segment
+    }
+    return result;
+}
+
 // sample_distance, woodcock_tracking.h:20-51.  `val` returns the intensity fetched by the accepted
 // iteration (= volume(PointOnRay(t)), the scatter point's intensity, pathtracer.cu:241).
 // rng_live: a random draw of this path can follow the walk; if not, and the walk provably cannot
@@ -199,6 +253,27 @@ SVR_DEV int walk_setup(const DevScene& s, const LDS& L, v3 orig, v3 dir, bool rn
         if (!COUNT && !rng_live && t_occ == u2f(SVR_INF_BITS)) return 0;
     }
     return 1;
+}
+
+// walk_setup for the primary walks of a full wave in frame-major order: the whole-ray test is shared by the lanes
+// that trace the same pixel (first_occupied_group).  Every lane of the wave must call it.
+template <bool COUNT, bool SKIP, typename LDS>
+SVR_DEV int walk_setup_group(const DevScene& s, const LDS& L, uint32_t P2, v3 orig, v3 dir, bool rng_live, float& tMin, float& tMax, float& t_occ)
+{
+    float tNear, tFar;
+    const bool hit = volume_intersect(s, orig, dir, tNear, tFar);
+    tMin = tNear < 0.f ? (float)1e-6 : tNear;
+    tMax = tFar;
+    t_occ = tMin;
+    if (SKIP && s.ray_skip) {
+        bool ok;
+        const float g = first_occupied_group(s, L, P2, orig, dir, hit, tMin, tMax, ok);
+        if (hit) {
+            t_occ = ok ? g : first_occupied(s, L, orig, dir, tMin, tMax);
+            if (!COUNT && !rng_live && t_occ == u2f(SVR_INF_BITS)) return 0;
+        }
+    }
+    return hit ? 1 : -1;
 }
 
 // REMARCH: a walk that comes out of an occupied stretch into clear space (two consecutive iterations in

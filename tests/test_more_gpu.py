@@ -322,3 +322,32 @@ def test_raycasting_lanes_per_ray(hip_dev, lanes_log2):
             canvas.close()
         assert np.array_equal(img, ref)
         assert cnt["raycast_steps"] == rc["raycast_steps"]
+
+
+@pytest.mark.parametrize("case", ["tiny_head", "small_head", "odd_thin_lens", "c3_window"])
+@pytest.mark.parametrize("nframes", [8, 16, 40])
+def test_frame_major_group_march(hip_dev, case, nframes):
+    """Many-frame launches put the frames of a pixel into one wave, and the lanes of a pixel share one whole-ray
+    test (first_occupied_group): counting and non-counting builds against the oracle.  tiny_head has one-voxel
+    macro-cells (most lanes fail the quarter-cell test and fall back to their own march), the thin-lens scene has
+    per-lane origins (every lane falls back), c3 is the benchmark configuration (every lane shares)."""
+    window = None
+    if case == "odd_thin_lens":
+        sc = _odd_scene(depth=1)
+    elif case == "c3_window":
+        sc = scenes.make_scene("c3")
+        window = (448, 480, 576, 520)
+        if nframes != 16:
+            pytest.skip("one frame count is enough at full size")
+    else:
+        sc = scenes.make_scene(case, trace_depth=2 if case == "tiny_head" else 1)
+    ref_hdr, _, ref_c = oracle_frames(sc, nframes, window=window)
+    for count in (False, True):
+        hdr, _, c = hip_frames(hip_dev, sc, nframes, batch=True, count=count, window=window)
+        if window:
+            x0, y0, x1, y1 = window
+            assert_bit_exact(hdr[y0:y1, x0:x1], ref_hdr[y0:y1, x0:x1], f"{case} {nframes} frames count={count}")
+        else:
+            assert_bit_exact(hdr, ref_hdr, f"{case} {nframes} frames count={count}")
+        if count:
+            assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"]
