@@ -63,9 +63,10 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
         if (SKIP && k == 0 && group_march) {
             // the wave is full and its lanes are pixels x frames: one shared whole-ray test per pixel
             float t_occ;
-            int r = walk_setup_group<COUNT, SKIP>(s, L_, P2, orig, dir, false, tMin, tMax, t_occ);
+            GroupMap map;
+            int r = walk_setup_group<COUNT, SKIP>(s, L_, P2, orig, dir, false, tMin, tMax, t_occ, map);
             t = r <= 0 ? -SVR_FLT_MAX
-                       : walk_run<LAYOUT, COUNT, SKIP, SVR_PRIMARY_REMARCH>(s, L_, orig, dir, rng, tMin, tMax, t_occ, val, false, c);
+                       : walk_run<LAYOUT, COUNT, SKIP, false, true>(s, L_, orig, dir, rng, tMin, tMax, t_occ, val, false, c, &map, P2);
         } else
             t = walk<LAYOUT, COUNT, SKIP, SVR_PRIMARY_REMARCH>(s, L_, orig, dir, rng, tMin, tMax, val, false, c);
         if (debug_stop == 3u) return V3(t, val, 0.f);
@@ -111,6 +112,7 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
             if (sample_light(s.lights[lightId], vs.pt, rng, wiL, pdfL, Li)) {
                 float sMin = (float)1e-6, sMax = SVR_FLT_MAX, sval = 0.f;
                 if (COUNT) c.shadow++;
+                if (debug_stop == 4u) return V3(wiL.x, pdfL, Li.x + vs.Pbrdf);
                 // the draws of sample_bsdf / roulette follow the shadow walk unless this is the last bounce
                 float ts = walk<LAYOUT, COUNT, SKIP, SVR_SHADOW_REMARCH>(s, L_, vs.pt, wiL, rng, sMin, sMax, sval, k + 1u < traceDepth, c);
                 float Tr = ((ts > sMin) && (ts < sMax)) ? 0.f : 1.f;          // transmittance.h:15-16
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 uint32_t r = (ty << th2) + (pl >> tw2);
                 const bool live = px < wv && r < w.n_rows && slot < w.nframes;
                 // shared whole-ray test: >= 8 frames of a pixel in the wave, every lane alive (the group shuffles)
-                const bool group_march = SKIP && fl2 >= 3u && w.debug_stop == 0u && __ballot(live) == ~0ull;
+                const bool group_march = SKIP && fl2 >= 3u && (w.debug_stop == 0u || w.debug_stop >= 3u) && __ballot(live) == ~0ull;
                 if (live) {
                     uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
                     v3 L = trace_path_tile<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, x, y, w.traceDepth, wang_hash(w.frame0 + slot), w.debug_stop, group_march, P2, c);

@@ -187,9 +187,40 @@ SVR_DEV float first_occupied(const DevScene& s, const LDS& L, v3 o, v3 d, float 
 // every point of its ray before the returned parameter is then within 0.95 cell (per axis) of an earlier, deep-empty
 // sample, i.e. in that cell or one of its 26 neighbours, which are all empty.  Lanes that fail the test (`ok` false:
 // thin lens, wide pixels on a coarse grid) fall back to their own DDA.  Must be called by all 64 lanes of the wave.
-template <typename LDS>
-SVR_DEV float first_occupied_group(const DevScene& s, const LDS& L, uint32_t P2, v3 o, v3 d, bool hit, float tMin, float tMax, bool& ok)
+//
+// The samples of the first GROUP_MAP_ROUNDS rounds are also kept as a bitmap (GroupMap): if they reach the end of the
+// segment, a lane can later ask in O(1) where the next possibly-occupied stretch after its current position starts
+// (group_map_next) -- the cheap stand-in for re-marching a primary walk that has come out of an occupied stretch.
+constexpr uint32_t GROUP_MAP_ROUNDS = 3;
+struct GroupMap {
+    float lo, dt, inv_dt;
+    uint64_t w[GROUP_MAP_ROUNDS];      // round r: bit (j << P2) = sample r * Lg + j is not deep-empty
+    bool valid;                        // the map covers the whole segment and this lane may use it
+};
+
+SVR_DEV float group_map_next(const GroupMap& g, uint32_t P2, float t)
 {
+    const uint32_t fl2 = 6u - P2, Lg = 64u >> P2;
+    // a sample at or before t (one earlier than the quotient says, against rounding): coverage from t_k includes t
+    int ki = (int)((t - g.lo) * g.inv_dt) - 1;
+    const uint32_t k = (uint32_t)(ki < 0 ? 0 : ki);
+    const uint32_t r = k >> fl2, j = k & (Lg - 1u);
+    uint64_t w0 = r == 0u ? g.w[0] : (r == 1u ? g.w[1] : (r == 2u ? g.w[2] : 0ull));
+    w0 >>= (j << P2);
+    if (w0) return fma_((float)(k + ((uint32_t)__builtin_ctzll(w0) >> P2)), g.dt, g.lo);
+    const uint64_t w1 = r == 0u ? g.w[1] : (r == 1u ? g.w[2] : 0ull);
+    if (w1) return fma_((float)(((r + 1u) << fl2) + ((uint32_t)__builtin_ctzll(w1) >> P2)), g.dt, g.lo);
+    const uint64_t w2 = r == 0u ? g.w[2] : 0ull;
+    if (w2) return fma_((float)(((r + 2u) << fl2) + ((uint32_t)__builtin_ctzll(w2) >> P2)), g.dt, g.lo);
+    return u2f(SVR_INF_BITS);
+}
+
+template <typename LDS>
+SVR_DEV float first_occupied_group(const DevScene& s, const LDS& L, uint32_t P2, v3 o, v3 d, bool hit, float tMin, float tMax, bool& ok,
+                                   GroupMap& map)
+{
+    map.valid = false; map.lo = 0.f; map.dt = 1.f; map.inv_dt = 1.f;
+    for (uint32_t r = 0; r < GROUP_MAP_ROUNDS; ++r) map.w[r] = 0ull;
     const float INF = u2f(SVR_INF_BITS);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t pl = lane & ((1u << P2) - 1u), m = lane >> P2, Lg = 64u >> P2;
@@ -218,7 +249,9 @@ SVR_DEV float first_occupied_group(const DevScene& s, const LDS& L, uint32_t P2,
     const int gx = s.mc_gx, gy = s.mc_gy, gz = s.mc_gz;
     const uint32_t* deep = L.mask;
     float result = INF;
-    for (uint32_t k0 = 0u; k0 < 4096u; k0 += Lg) {
+    bool found = false, complete = false;
+    uint32_t round = 0;
+    for (uint32_t k0 = 0u; k0 < 4096u; k0 += Lg, ++round) {
         const float tk = fma_((float)(k0 + m), dt, lo);
         const int ix = min(max((int)__builtin_floorf(fma_(Bx, tk, Ax)), 0), gx - 1);
         const int iy = min(max((int)__builtin_floorf(fma_(By, tk, Ay)), 0), gy - 1);
@@ -226,9 +259,14 @@ SVR_DEV float first_occupied_group(const DevScene& s, const LDS& L, uint32_t P2,
         const uint32_t q = (uint32_t)(ix + iy * gx + iz * s.mc_gxy);
         const bool occupied = (tk <= hi) && !((deep[q >> 5] >> (q & 31u)) & 1u);
         const uint64_t b = __ballot(occupied) & gmask;
-        if (b) { result = fma_((float)(k0 + (((uint32_t)__builtin_ctzll(b) - pl) >> P2)), dt, lo); break; }
-        if (fma_((float)(k0 + Lg - 1u), dt, lo) > hi) break;        // the round reached the end of the segment
+        if (round < GROUP_MAP_ROUNDS) map.w[round] = b >> pl;
+        if (b && !found) { found = true; result = fma_((float)(k0 + (((uint32_t)__builtin_ctzll(b) - pl) >> P2)), dt, lo); }
+        const bool at_end = fma_((float)(k0 + Lg - 1u), dt, lo) > hi;      // the round reached the end of the segment
+        if (at_end) { complete = round < GROUP_MAP_ROUNDS; break; }
+        if (found && round + 1u >= GROUP_MAP_ROUNDS) break;                // the map cannot be completed: stop at the first hit
     }
+    map.lo = lo; map.dt = dt; map.inv_dt = bmax * (1.f / 0.7f);
+    map.valid = complete && ok;
     return result;
 }
 
@@ -258,8 +296,10 @@ SVR_DEV int walk_setup(const DevScene& s, const LDS& L, v3 orig, v3 dir, bool rn
 // walk_setup for the primary walks of a full wave in frame-major order: the whole-ray test is shared by the lanes
 // that trace the same pixel (first_occupied_group).  Every lane of the wave must call it.
 template <bool COUNT, bool SKIP, typename LDS>
-SVR_DEV int walk_setup_group(const DevScene& s, const LDS& L, uint32_t P2, v3 orig, v3 dir, bool rng_live, float& tMin, float& tMax, float& t_occ)
+SVR_DEV int walk_setup_group(const DevScene& s, const LDS& L, uint32_t P2, v3 orig, v3 dir, bool rng_live, float& tMin, float& tMax, float& t_occ,
+                             GroupMap& map)
 {
+    map.valid = false;
     float tNear, tFar;
     const bool hit = volume_intersect(s, orig, dir, tNear, tFar);
     tMin = tNear < 0.f ? (float)1e-6 : tNear;
@@ -267,7 +307,7 @@ SVR_DEV int walk_setup_group(const DevScene& s, const LDS& L, uint32_t P2, v3 or
     t_occ = tMin;
     if (SKIP && s.ray_skip) {
         bool ok;
-        const float g = first_occupied_group(s, L, P2, orig, dir, hit, tMin, tMax, ok);
+        const float g = first_occupied_group(s, L, P2, orig, dir, hit, tMin, tMax, ok, map);
         if (hit) {
             t_occ = ok ? g : first_occupied(s, L, orig, dir, tMin, tMax);
             if (!COUNT && !rng_live && t_occ == u2f(SVR_INF_BITS)) return 0;
@@ -282,9 +322,12 @@ SVR_DEV int walk_setup_group(const DevScene& s, const LDS& L, uint32_t P2, v3 or
 // slower than not marching at all).  If nothing occupied lies ahead and no draw follows the walk, its result
 // (-FLT_MAX) is known; otherwise it resumes with the new t_occ.  COUNT builds keep iterating instead so that
 // the iteration/tap counters stay the reference's.
-template <int LAYOUT, bool COUNT, bool SKIP, bool REMARCH, typename LDS>
+// MAP: the walk belongs to a pixel group with a GroupMap (primary walks of frame-major launches): an iteration that
+// lands in an empty cell asks the map for the next possibly-occupied stretch and, if that lies ahead, goes back to
+// fetch-free iterations until then (or ends, if nothing lies ahead and no draw follows the walk).
+template <int LAYOUT, bool COUNT, bool SKIP, bool REMARCH, bool MAP, typename LDS>
 SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float tMin, float tMax, float t_occ,
-                       float& val, bool rng_live, Cnt& c)
+                       float& val, bool rng_live, Cnt& c, const GroupMap* map = nullptr, uint32_t P2 = 0u)
 {
     float t = tMin;
     const bool ray_skippable = SKIP && s.ray_skip && !rng_live && t_occ == u2f(SVR_INF_BITS);
@@ -317,7 +360,7 @@ SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rn
             pending = false;
             float sigma_t = 0.f;
             bool park_now = false;
-            {
+            if (!MAP || t >= t_occ) {
                 v3 p = orig + dir * t;
                 Cell cell = cell_of(s, p);
                 bool fetch = true;
@@ -327,6 +370,17 @@ SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rn
                     val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
                     sigma_t = alpha_of(L, s, val);
                     clear_run = 0;
+                } else if (SKIP && MAP) {
+                    if (map->valid) {
+                        t_occ = group_map_next(*map, P2, t);          // <= t while the walk is in or next to an occupied stretch
+                        if (t_occ == u2f(SVR_INF_BITS) && !rng_live) {
+                            if (!COUNT) {
+                                // consume nothing further: the walk cannot collide any more and no draw follows it
+                                return -SVR_FLT_MAX;
+                            }
+                            if (!tail_counted) { tail_counted = true; c.wskip++; }
+                        }
+                    }
                 } else if (SKIP && REMARCH) {
                     // park after two consecutive iterations in DEEP-empty cells (where a march can start)
                     clear_run = cell_is_empty<true>(L, s, cell) ? clear_run + 1u : 0u;
@@ -354,7 +408,7 @@ SVR_DEV float walk(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, f
     float t_occ;
     int r = walk_setup<COUNT, SKIP>(s, L, orig, dir, rng_live, tMin, tMax, t_occ);
     if (r <= 0) return -SVR_FLT_MAX;
-    return walk_run<LAYOUT, COUNT, SKIP, REMARCH>(s, L, orig, dir, rng, tMin, tMax, t_occ, val, rng_live, c);
+    return walk_run<LAYOUT, COUNT, SKIP, REMARCH, false>(s, L, orig, dir, rng, tMin, tMax, t_occ, val, rng_live, c);
 }
 
 } // namespace svr
