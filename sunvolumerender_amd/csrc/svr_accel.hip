@@ -79,37 +79,90 @@ hipError_t launch_minmax(const uint16_t* src, uint16_t* mm, int nx, int ny, int 
     return hipGetLastError();
 }
 
-// deep-empty: the macro-cell and all its in-grid neighbours (3x3x3) are empty.  A ray marched through
-// the macro grid in float arithmetic can be off by far less than one macro-cell, so "every visited
-// cell is deep-empty" proves that every fetch along the ray lies in an empty macro-cell.
-__global__ __launch_bounds__(256) void k_deep_mask(const uint32_t* __restrict__ empty, uint32_t* __restrict__ deep,
-                                                   int gx, int gy, int gz)
+// Distance field over the macro grid: D(c) = Chebyshev distance (in macro-cells, capped at 15) from cell c to the
+// nearest macro-cell that is NOT empty; cells outside the grid count as empty (no fetch ever happens there).
+// D(c) >= 1 <=> c is empty; D(c) >= 2 <=> c and its 26 neighbours are empty ("deep-empty"); in general every cell
+// within Chebyshev distance D(c) - 1 of c is empty, so a ray at a point of c may advance until its largest-axis
+// displacement reaches D(c) - 1 cells without meeting a fetch that could return a non-zero opacity.  A march
+// through the grid in float arithmetic is off by far less than one macro-cell.
+// Built separably (x, then y, then z: min over the offset of max(|offset|, previous)), then stored at HALF
+// resolution (minimum over the 2x2x2 children, 4 bits per coarse cell: <= 16 KB for a 64^3 grid) -- that is what
+// the kernels keep in LDS next to the `empty` bitmask.
+__global__ __launch_bounds__(256) void k_dist_axis(const uint32_t* __restrict__ empty, const uint8_t* __restrict__ in,
+                                                   uint8_t* __restrict__ out, int gx, int gy, int gz, int axis)
 {
     uint32_t m = blockIdx.x * 256u + threadIdx.x;
     uint32_t n = (uint32_t)gx * (uint32_t)gy * (uint32_t)gz;
     if (m >= n) return;
-    int mx = (int)(m % (uint32_t)gx), my = (int)((m / (uint32_t)gx) % (uint32_t)gy), mz = (int)(m / ((uint32_t)gx * (uint32_t)gy));
-    bool all = true;
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                int x = mx + dx, y = my + dy, z = mz + dz;
-                if (x < 0 || y < 0 || z < 0 || x >= gx || y >= gy || z >= gz) continue;
-                uint32_t q = (uint32_t)x + (uint32_t)gx * ((uint32_t)y + (uint32_t)gy * (uint32_t)z);
-                all = all && ((empty[q >> 5] >> (q & 31u)) & 1u);
-            }
-    if (all) atomicOr(&deep[m >> 5], 1u << (m & 31u));
+    int c[3] = {(int)(m % (uint32_t)gx), (int)((m / (uint32_t)gx) % (uint32_t)gy), (int)(m / ((uint32_t)gx * (uint32_t)gy))};
+    const int g[3] = {gx, gy, gz};
+    const int stride = axis == 0 ? 1 : (axis == 1 ? gx : gx * gy);
+    int best = DIST_CAP;
+    for (int o = -(DIST_CAP - 1); o <= DIST_CAP - 1; ++o) {
+        int p = c[axis] + o;
+        if (p < 0 || p >= g[axis]) continue;                       // outside the grid: empty, infinitely far
+        uint32_t q = (uint32_t)((int)m + o * stride);
+        int d = axis == 0 ? (((empty[q >> 5] >> (q & 31u)) & 1u) ? DIST_CAP : 0) : (int)in[q];
+        int a = o < 0 ? -o : o;
+        d = d > a ? d : a;
+        best = d < best ? d : best;
+    }
+    out[m] = (uint8_t)best;
 }
 
+__global__ __launch_bounds__(256) void k_dist_pack(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, int gx, int gy, int gz,
+                                                   int hgx, int hgy, int hgz, uint32_t words)
+{
+    uint32_t wi = blockIdx.x * 256u + threadIdx.x;
+    if (wi >= words) return;
+    const uint32_t hn = (uint32_t)hgx * (uint32_t)hgy * (uint32_t)hgz;
+    uint32_t word = 0u;
+    for (uint32_t k = 0; k < 8u; ++k) {
+        uint32_t hq = wi * 8u + k;
+        if (hq >= hn) break;
+        int hx = (int)(hq % (uint32_t)hgx), hy = (int)((hq / (uint32_t)hgx) % (uint32_t)hgy), hz = (int)(hq / ((uint32_t)hgx * (uint32_t)hgy));
+        int best = DIST_CAP;
+        for (int dz = 0; dz < 2; ++dz)
+            for (int dy = 0; dy < 2; ++dy)
+                for (int dx = 0; dx < 2; ++dx) {
+                    int x = 2 * hx + dx, y = 2 * hy + dy, z = 2 * hz + dz;
+                    if (x >= gx || y >= gy || z >= gz) continue;
+                    int d = in[(uint32_t)x + (uint32_t)gx * ((uint32_t)y + (uint32_t)gy * (uint32_t)z)];
+                    best = d < best ? d : best;
+                }
+        word |= (uint32_t)best << (4u * k);
+    }
+    out[wi] = word;
+}
+
+// deep-empty bit of a macro-cell: distance >= 2, i.e. the cell and its 26 in-grid neighbours are empty (full resolution)
+__global__ __launch_bounds__(256) void k_deep_mask(const uint8_t* __restrict__ dist, uint32_t* __restrict__ deep, uint32_t n)
+{
+    uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m < n && dist[m] >= 2) atomicOr(&deep[m >> 5], 1u << (m & 31u));
+}
+
+// mask: DIST_WORDS_MAX words of packed half-resolution distances, MASK_WORDS_MAX words of deep-empty bits,
+// then mask_words words of `empty` bits; tmp: 2 x n_cells bytes
 hipError_t launch_empty_mask(const uint16_t* mm, int gx, int gy, int gz, const uint32_t* tf_zero_prefix, int tf_n,
-                             float densityScale, uint32_t* mask, uint32_t mask_words, hipStream_t st)
+                             float densityScale, uint32_t* mask, uint32_t mask_words, uint8_t* tmp, hipStream_t st)
 {
     uint32_t n_cells = (uint32_t)gx * (uint32_t)gy * (uint32_t)gz;
-    hipError_t e = hipMemsetAsync(mask, 0, (size_t)mask_words * 8u, st);
+    uint32_t* deep = mask + DIST_WORDS_MAX;
+    uint32_t* empty = mask + DIST_WORDS_MAX + MASK_WORDS_MAX;
+    hipError_t e = hipMemsetAsync(deep, 0, (size_t)(MASK_WORDS_MAX + mask_words) * 4u, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_empty_mask, dim3((n_cells + 255u) / 256u), dim3(256), 0, st, mm, n_cells,
-                       tf_zero_prefix, tf_n, densityScale, mask + mask_words);
-    hipLaunchKernelGGL(k_deep_mask, dim3((n_cells + 255u) / 256u), dim3(256), 0, st, mask + mask_words, mask, gx, gy, gz);
+    const uint32_t blocks = (n_cells + 255u) / 256u;
+    hipLaunchKernelGGL(k_empty_mask, dim3(blocks), dim3(256), 0, st, mm, n_cells, tf_zero_prefix, tf_n, densityScale, empty);
+    uint8_t* a = tmp;
+    uint8_t* b = tmp + n_cells;
+    hipLaunchKernelGGL(k_dist_axis, dim3(blocks), dim3(256), 0, st, empty, (const uint8_t*)nullptr, a, gx, gy, gz, 0);
+    hipLaunchKernelGGL(k_dist_axis, dim3(blocks), dim3(256), 0, st, empty, a, b, gx, gy, gz, 1);
+    hipLaunchKernelGGL(k_dist_axis, dim3(blocks), dim3(256), 0, st, empty, b, a, gx, gy, gz, 2);
+    const int hgx = (gx + 1) / 2, hgy = (gy + 1) / 2, hgz = (gz + 1) / 2;
+    const uint32_t words = ((uint32_t)hgx * (uint32_t)hgy * (uint32_t)hgz + 7u) / 8u;
+    hipLaunchKernelGGL(k_deep_mask, dim3(blocks), dim3(256), 0, st, a, deep, n_cells);
+    hipLaunchKernelGGL(k_dist_pack, dim3((words + 255u) / 256u), dim3(256), 0, st, a, mask, gx, gy, gz, hgx, hgy, hgz, words);
     return hipGetLastError();
 }
 

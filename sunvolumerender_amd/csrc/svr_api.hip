@@ -100,6 +100,7 @@ struct Context {
     int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
+    uint8_t* d_mask_tmp = nullptr;     // scratch of the distance transform
     bool mask_valid = false;
     uint64_t mask_vol = 0, mask_tf = 0, mask_tf_version = 0;
     uint32_t mask_ds_bits = 0;
@@ -165,7 +166,8 @@ int ensure_init()
     HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
     HIP_TRY(hipMalloc((void**)&g.d_ticket, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * Context::NSETS));
     HIP_TRY(hipMemset(g.d_ticket, 0, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * Context::NSETS));
-    HIP_TRY(hipMalloc((void**)&g.d_mask, 2 * svr::MASK_WORDS_MAX * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&g.d_mask, (svr::DIST_WORDS_MAX + 2 * svr::MASK_WORDS_MAX) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&g.d_mask_tmp, 2 * (size_t)svr::MASK_WORDS_MAX * 32));
     for (int i = 0; i < Context::NSETS; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&g.sets[i].stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&g.sets[i].traced, hipEventDisableTiming));
@@ -358,13 +360,18 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
           g.mask_ds_bits == ds_bits)) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(svr::launch_empty_mask(tv->mm, tv->mc_gx, tv->mc_gy, tv->mc_gz, tt->zero_prefix, tt->nx,
-                                       vol.densityScale, g.d_mask, words, g.stream));
+                                       vol.densityScale, g.d_mask, words, g.d_mask_tmp, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
         g.mask_valid = true; g.mask_vol = vol.tex; g.mask_tf = tf.tex; g.mask_tf_version = tt->version;
         g.mask_ds_bits = ds_bits; g.mask_words = words;
     }
     s.empty_mask = g.d_mask;
     s.mask_words = g.mask_words;
+    {
+        const int hgx = (tv->mc_gx + 1) / 2, hgy = (tv->mc_gy + 1) / 2, hgz = (tv->mc_gz + 1) / 2;
+        s.mc_hgx = hgx; s.mc_hgxy = hgx * hgy;
+        s.dist_words = ((uint32_t)hgx * (uint32_t)hgy * (uint32_t)hgz + 7u) / 8u;
+    }
     s.mc_shift = tv->mc_shift;
     s.mc_gx = tv->mc_gx; s.mc_gy = tv->mc_gy; s.mc_gz = tv->mc_gz;
     s.mc_gxy = tv->mc_gx * tv->mc_gy;
@@ -540,6 +547,7 @@ void svr_shutdown(void)
         if (st.resolved) hipEventDestroy(st.resolved);
     }
     if (g.d_mask) hipFree(g.d_mask);
+    if (g.d_mask_tmp) hipFree(g.d_mask_tmp);
     if (g.d_counters) hipFree(g.d_counters);
     if (g.d_ticket) hipFree(g.d_ticket);
     for (int i = 0; i < Context::EV_RING; ++i) {

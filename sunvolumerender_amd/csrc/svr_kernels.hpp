@@ -10,7 +10,9 @@ enum { KERNEL_AUTO = 0, KERNEL_PIXEL = 1, KERNEL_TILE = 2, KERNEL_ULOOP = 3, KER
 constexpr int WF_QUEUE_PLANES = 18;         // 2 ray queues + 1 hit queue, 6 float4 planes each
 constexpr uint32_t TICKET_SHARDS = 8;       // sharded work counters (one per XCD group), 128 B apart
 constexpr uint32_t TICKET_STRIDE = 32;      // in uint32 words
-constexpr uint32_t MASK_WORDS_MAX = 8192;   // words of the LDS-resident bitmask (32 KiB): up to 64^3 macro-cells
+constexpr uint32_t MASK_WORDS_MAX = 8192;   // words of the LDS-resident `empty` bitmask (32 KiB): up to 64^3 macro-cells
+constexpr uint32_t DIST_WORDS_MAX = 4096;   // words of the half-resolution 4-bit distance field (16 KiB): up to 32^3 coarse cells
+constexpr int DIST_CAP = 15;
 
 // counter slots (unsigned long long each) -- order of svr_counters in include/svr_abi.h
 enum { CNT_PATHS = 0, CNT_VOL_TAPS, CNT_WOODCOCK, CNT_SCATTER, CNT_SHADOW, CNT_RAYCAST, CNT_LOOP, CNT_TAPS_EXEC,
@@ -38,10 +40,11 @@ hipError_t launch_wavefront(const DevScene& scene, const DevWork& work, const La
 // acceleration data (svr_accel.hip): per-macro-cell min/max of the raw voxels, and the empty bitmask
 hipError_t launch_minmax(const uint16_t* src_linear, uint16_t* mm, int nx, int ny, int nz, int shift,
                          int gx, int gy, int gz, hipStream_t stream);
-// mask: 2*mask_words words; [0, mask_words) = deep-empty bits (macro-cell and its 26 neighbours all empty;
-// the only mask the trace kernel reads), [mask_words, 2*mask_words) = plain empty bits (scratch)
+// mask: [0, DIST_WORDS_MAX) = half-resolution 4-bit distance field (distance to the nearest non-empty macro-cell),
+// then MASK_WORDS_MAX words of deep-empty bits (distance >= 2, full resolution), then mask_words words of `empty`
+// bits; tmp: 2 * gx*gy*gz bytes of scratch
 hipError_t launch_empty_mask(const uint16_t* mm, int gx, int gy, int gz, const uint32_t* tf_zero_prefix, int tf_n,
-                             float densityScale, uint32_t* mask, uint32_t mask_words, hipStream_t stream);
+                             float densityScale, uint32_t* mask, uint32_t mask_words, uint8_t* tmp, hipStream_t stream);
 // hdr_to_ldr over the owned pixels
 hipError_t launch_tonemap(const DevScene& scene, const DevWork& work, hipStream_t stream);
 // kernel_raycasting over the owned pixels

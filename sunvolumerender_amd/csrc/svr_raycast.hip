@@ -25,6 +25,7 @@ namespace svr {
 
 struct LdsRaycast {
     float4 rgba[SVR_TF_MAX + SVR_TF_PAD];      // entry e = texel clamp(e-1)
+    uint32_t dist[1];
     uint32_t mask[1];
     uint32_t emask[MASK_WORDS_MAX];
 };
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(SVR_RC_THREADS) void k_raycast(const DevScene s, co
         const float4* g = reinterpret_cast<const float4*>(s.tf);
         for (int e = threadIdx.x; e < n + SVR_TF_PAD; e += SVR_RC_THREADS) L.rgba[e] = g[min(max(e - 1, 0), n - 1)];
         if (SKIP) {
-            const uint4* src = reinterpret_cast<const uint4*>(s.empty_mask + s.mask_words);
+            const uint4* src = reinterpret_cast<const uint4*>(s.empty_mask + DIST_WORDS_MAX + MASK_WORDS_MAX);
             uint4* dst = reinterpret_cast<uint4*>(L.emask);
             for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += SVR_RC_THREADS) dst[q] = src[q];
         }

@@ -41,9 +41,10 @@ struct DevScene {
     int32_t bnx, bny;              // BRICK: bricks per row / per slab-row
     // empty-space bitmask (one bit per macro-cell of 2^mc_shift cells per axis; bit set = every
     // trilinear fetch whose cell lies in the macro-cell has transfer-function alpha exactly 0)
-    const uint32_t* empty_mask;    // device: mask_words words of deep-empty bits, then mask_words words of empty bits; null = no skipping
+    const uint32_t* empty_mask;    // device: DIST_WORDS_MAX words of packed half-resolution distances, MASK_WORDS_MAX words of deep-empty bits, mask_words words of empty bits; null = no skipping
     int32_t mc_shift, mc_gx, mc_gy, mc_gz, mc_gxy;
-    uint32_t mask_words;
+    int32_t mc_hgx, mc_hgxy;       // half-resolution grid of the distance field: row and slice strides
+    uint32_t mask_words, dist_words;
     uint32_t ray_skip;             // 1: the clipped box lies inside the texture domain, so whole-ray tests are valid
     float mc_scale[3];             // macro-grid coordinate = (p - vmin) * mc_scale + mc_off
     float mc_off;

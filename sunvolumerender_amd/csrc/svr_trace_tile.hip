@@ -142,7 +142,7 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
 #define SVR_TILE_WAVES_PER_EU 4
 #endif
 #ifndef SVR_TILE_THREADS
-#define SVR_TILE_THREADS 512      // 8 waves share one 68 KB LDS image (alpha LUT + two 32 KB masks): 2 blocks = 16 waves per CU
+#define SVR_TILE_THREADS 1024     // 16 waves share one 84 KB LDS image (alpha LUT, two 32 KB bitmasks, 16 KB distance field): one block per CU
 #endif
 
 template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1>

@@ -1,5 +1,5 @@
 // svr_walk.hpp -- the Woodcock-walk machinery shared by the tile kernel (svr_trace_tile.hip) and the
-// wavefront kernels (svr_wavefront.hip): LDS-resident alpha LUT + deep-empty bitmask, the software
+// wavefront kernels (svr_wavefront.hip): LDS-resident alpha LUT + empty bitmask + distance field, the software
 // tex3D (cell + fetch), the conservative whole-ray march, and the walk loop itself.
 #pragma once
 #include "svr_kernel_common.hpp"
@@ -8,11 +8,13 @@ namespace svr {
 
 struct LdsTile {
     float alpha[SVR_TF_MAX + SVR_TF_PAD];      // entry e = alpha of texel clamp(e-1)
-    uint32_t mask[MASK_WORDS_MAX];             // deep-empty bits: the macro-cell and its 26 neighbours are transparent (ray march)
+    uint32_t dist[DIST_WORDS_MAX];             // 4-bit distance (macro-cells, half resolution) to the nearest non-empty macro-cell (long leaps of a march)
+    uint32_t mask[MASK_WORDS_MAX];             // deep-empty bits (distance >= 2 at full resolution): the macro-cell and its 26 neighbours are transparent
     uint32_t emask[MASK_WORDS_MAX];            // empty bits: the macro-cell itself is transparent (per-fetch test, exact cell index)
 };
 struct LdsTileNoMask {
     float alpha[SVR_TF_MAX + SVR_TF_PAD];
+    uint32_t dist[1];
     uint32_t mask[1];
     uint32_t emask[1];
 };
@@ -27,9 +29,12 @@ SVR_DEV void lds_tile_load(LDS& L, const DevScene& s, bool with_mask)
     }
     if (with_mask) {
         const uint4* src = reinterpret_cast<const uint4*>(s.empty_mask);
-        uint4* dst = reinterpret_cast<uint4*>(L.mask);
-        for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += blockDim.x) dst[q] = src[q];
-        const uint4* src2 = reinterpret_cast<const uint4*>(s.empty_mask + s.mask_words);
+        uint4* dst = reinterpret_cast<uint4*>(L.dist);
+        for (uint32_t q = threadIdx.x; q < (s.dist_words + 3u) / 4u; q += blockDim.x) dst[q] = src[q];
+        const uint4* src1 = reinterpret_cast<const uint4*>(s.empty_mask + DIST_WORDS_MAX);
+        uint4* dst1 = reinterpret_cast<uint4*>(L.mask);
+        for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += blockDim.x) dst1[q] = src1[q];
+        const uint4* src2 = reinterpret_cast<const uint4*>(s.empty_mask + DIST_WORDS_MAX + MASK_WORDS_MAX);
         uint4* dst2 = reinterpret_cast<uint4*>(L.emask);
         for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += blockDim.x) dst2[q] = src2[q];
     }
@@ -113,7 +118,15 @@ SVR_DEV float alpha_of(const LDS& L, const DevScene& s, float x)
     return lerpf(L.alpha[e], L.alpha[e + 1], a);
 }
 
-// macro-cell bit of a trilinear cell.  The mask covers the cells c = -1 .. N-1 (c+1 in [0, N]: every cell
+// distance-field entry of macro-cell (ix, iy, iz) (in-grid): every macro-cell within Chebyshev distance d - 1 is empty
+template <typename LDS>
+SVR_DEV uint32_t dist_at(const LDS& L, const DevScene& s, uint32_t ix, uint32_t iy, uint32_t iz)
+{
+    const uint32_t hq = (ix >> 1) + __umul24(iy >> 1, (uint32_t)s.mc_hgx) + __umul24(iz >> 1, (uint32_t)s.mc_hgxy);
+    return (L.dist[hq >> 3] >> ((hq & 7u) << 2)) & 15u;
+}
+
+// macro-cell of a trilinear cell.  The grid covers the cells c = -1 .. N-1 (c+1 in [0, N]: every cell
 // a point of the texture domain maps to); cells further out (clip planes beyond the volume, gradient
 // taps) always fetch.
 // deep = false: the macro-cell is transparent (no fetch needed); deep = true: so are its 26 neighbours
@@ -131,51 +144,39 @@ SVR_DEV bool cell_is_empty(const LDS& L, const DevScene& s, const Cell& c)
     return inb && ((word >> (m & 31u)) & 1u);
 }
 
-// Conservative march of the ray segment [t0, t1] through the macro grid (3D-DDA): returns the ray
-// parameter at which the segment first enters a macro-cell that is not deep-empty, or +inf if it
-// never does.  Float error in the march is far below one macro-cell, and a deep-empty cell has only
-// empty neighbours, so every point of the ray with t < result lies in an empty macro-cell.
+// Conservative march of the ray segment [t0, t1] through the macro grid: returns a ray parameter before which
+// every point of the segment lies in an empty macro-cell (and at which a cell next to a non-empty one is reached), or
+// +inf if the whole segment is clear.  Sphere tracing on the distance field: from a point whose cell has distance d,
+// the ray may advance until its largest-axis displacement is d - 1 cells (0.05 cell of margin covers the float error
+// of the march, which is far below one macro-cell).  ~10 steps for a ray that crosses a 64^3 grid, against ~100 cell
+// crossings of a 3D-DDA.
 template <typename LDS>
 SVR_DEV float first_occupied(const DevScene& s, const LDS& L, v3 o, v3 d, float t0, float t1)
 {
     const float INF = u2f(SVR_INF_BITS);
-    float Ax = fma_(o.x - s.vmin[0], s.mc_scale[0], s.mc_off), Bx = d.x * s.mc_scale[0];
-    float Ay = fma_(o.y - s.vmin[1], s.mc_scale[1], s.mc_off), By = d.y * s.mc_scale[1];
-    float Az = fma_(o.z - s.vmin[2], s.mc_scale[2], s.mc_off), Bz = d.z * s.mc_scale[2];
+    const float Ax = fma_(o.x - s.vmin[0], s.mc_scale[0], s.mc_off), Bx = d.x * s.mc_scale[0];
+    const float Ay = fma_(o.y - s.vmin[1], s.mc_scale[1], s.mc_off), By = d.y * s.mc_scale[1];
+    const float Az = fma_(o.z - s.vmin[2], s.mc_scale[2], s.mc_off), Bz = d.z * s.mc_scale[2];
+    const float bmax = fmax_(__builtin_fabsf(Bx), fmax_(__builtin_fabsf(By), __builtin_fabsf(Bz)));
+    if (!(bmax > 0.f)) return t0;                 // degenerate direction: no skipping
+    const float inv = __builtin_amdgcn_rcpf(bmax) * 0.999f;
     const int gx = s.mc_gx, gy = s.mc_gy, gz = s.mc_gz;
-    int ix = min(max((int)__builtin_floorf(fma_(Bx, t0, Ax)), 0), gx - 1);
-    int iy = min(max((int)__builtin_floorf(fma_(By, t0, Ay)), 0), gy - 1);
-    int iz = min(max((int)__builtin_floorf(fma_(Bz, t0, Az)), 0), gz - 1);
-    const bool px = Bx > 0.f, py = By > 0.f, pz = Bz > 0.f;
-    float rx = __builtin_amdgcn_rcpf(Bx), ry = __builtin_amdgcn_rcpf(By), rz = __builtin_amdgcn_rcpf(Bz);
-    // next face crossing and per-cell increment along each axis (+inf for an axis the ray does not move along)
-    float tnx = (Bx != 0.f) ? ((float)(ix + (px ? 1 : 0)) - Ax) * rx : INF;
-    float tny = (By != 0.f) ? ((float)(iy + (py ? 1 : 0)) - Ay) * ry : INF;
-    float tnz = (Bz != 0.f) ? ((float)(iz + (pz ? 1 : 0)) - Az) * rz : INF;
-    const float dtx = (Bx != 0.f) ? __builtin_fabsf(rx) : INF, dty = (By != 0.f) ? __builtin_fabsf(ry) : INF,
-                dtz = (Bz != 0.f) ? __builtin_fabsf(rz) : INF;
-    // linear cell index and its per-axis increments; cells left before the ray would step out of the grid
-    int q = ix + iy * gx + iz * s.mc_gxy;
-    const int qsx = px ? 1 : -1, qsy = py ? gx : -gx, qsz = pz ? s.mc_gxy : -s.mc_gxy;
-    int nx = px ? gx - 1 - ix : ix, ny = py ? gy - 1 - iy : iy, nz = pz ? gz - 1 - iz : iz;
     float t = t0;
-    const uint32_t* deep = L.mask;
-    const int guard = gx + gy + gz + 4;
-    for (int it = 0; it < guard; ++it) {
-        if (!((deep[(uint32_t)q >> 5] >> ((uint32_t)q & 31u)) & 1u)) return t;
-        float tn = fmin_(tnx, fmin_(tny, tnz));
-        if (!(tn <= t1)) return INF;          // the segment ends inside this cell
-        t = tn;
-        // branch-free step along the axis of the nearest face
-        const bool sx = tnx <= tny && tnx <= tnz;
-        const bool sy = !sx && tny <= tnz;
-        const bool sz = !sx && !sy;
-        tnx += sx ? dtx : 0.f;  tny += sy ? dty : 0.f;  tnz += sz ? dtz : 0.f;
-        q += sx ? qsx : (sy ? qsy : qsz);
-        nx -= sx ? 1 : 0;  ny -= sy ? 1 : 0;  nz -= sz ? 1 : 0;
-        if ((nx | ny | nz) < 0) return INF;    // stepped out of the grid
+    for (int it = 0; it < 512; ++it) {
+        const uint32_t ix = (uint32_t)min(max((int)__builtin_floorf(fma_(Bx, t, Ax)), 0), gx - 1);
+        const uint32_t iy = (uint32_t)min(max((int)__builtin_floorf(fma_(By, t, Ay)), 0), gy - 1);
+        const uint32_t iz = (uint32_t)min(max((int)__builtin_floorf(fma_(Bz, t, Az)), 0), gz - 1);
+        uint32_t dd = dist_at(L, s, ix, iy, iz);
+        if (dd < 2u) {
+            // close to something at half resolution: decide on the full-resolution deep-empty bit
+            const uint32_t q = ix + __umul24(iy, (uint32_t)gx) + __umul24(iz, (uint32_t)s.mc_gxy);
+            if (!((L.mask[q >> 5] >> (q & 31u)) & 1u)) return t;
+            dd = 2u;
+        }
+        t = fma_((float)dd - 1.05f, inv, t);
+        if (t > t1) return INF;
     }
-    return t;   // guard exhausted (cannot happen: each step leaves a cell): treat the rest as occupied
+    return t;   // step budget exhausted: treat the rest as occupied
 }
 
 // The same question for a GROUP of lanes at once.  With frame-major lanes (svr_trace_tile.hip) the 1 << fl2 lanes
@@ -247,7 +248,6 @@ SVR_DEV float first_occupied_group(const DevScene& s, const LDS& L, uint32_t P2,
                                0x0001000100010001ull, 0x0000000100000001ull, 1ull};
     const uint64_t gmask = every[P2] << pl;
     const int gx = s.mc_gx, gy = s.mc_gy, gz = s.mc_gz;
-    const uint32_t* deep = L.mask;
     float result = INF;
     bool found = false, complete = false;
     uint32_t round = 0;
@@ -257,7 +257,7 @@ SVR_DEV float first_occupied_group(const DevScene& s, const LDS& L, uint32_t P2,
         const int iy = min(max((int)__builtin_floorf(fma_(By, tk, Ay)), 0), gy - 1);
         const int iz = min(max((int)__builtin_floorf(fma_(Bz, tk, Az)), 0), gz - 1);
         const uint32_t q = (uint32_t)(ix + iy * gx + iz * s.mc_gxy);
-        const bool occupied = (tk <= hi) && !((deep[q >> 5] >> (q & 31u)) & 1u);
+        const bool occupied = (tk <= hi) && !((L.mask[q >> 5] >> (q & 31u)) & 1u);
         const uint64_t b = __ballot(occupied) & gmask;
         if (round < GROUP_MAP_ROUNDS) map.w[round] = b >> pl;
         if (b && !found) { found = true; result = fma_((float)(k0 + (((uint32_t)__builtin_ctzll(b) - pl) >> P2)), dt, lo); }
