@@ -84,7 +84,8 @@ struct Context {
 #ifndef SVR_GROUP
 #define SVR_GROUP 32     // frames per trace launch: 8 / 16 / 32 / 64 measured 0.185 / 0.178 / 0.166 / 0.161 ms per frame on c3
 #endif
-    static constexpr int NSETS = 4, GROUP = SVR_GROUP, CHAIN_MIN_FRAMES = 8;
+    static constexpr int NSETS = 4, GROUP = SVR_GROUP;
+    static constexpr uint64_t CHAIN_MIN_PATHS = 12u << 20;   // paths of a trace launch from which launches are chained
     struct SlotSet {
         float* lbuf = nullptr;
         hipStream_t stream = nullptr;
@@ -471,10 +472,11 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         w.nframes = n;
         // the scratch slots of this set are free again once their previous resolve has run
         if (g.opt_pipeline && set.used) HIP_TRY(hipStreamWaitEvent(ts, set.resolved, 0));
-        // A many-frame trace launch fills the chip by itself; running two of them at once only makes them share
-        // L2 and stretches both.  They are chained (the resolve of one still overlaps the trace of the next);
-        // few-frame launches (interactive use, one frame per call) overlap freely to hide each other's tails.
-        if (g.opt_pipeline && n >= (uint32_t)Context::CHAIN_MIN_FRAMES && g.prev_traced)
+        // A large trace launch fills the chip by itself; running two of them at once only makes them share L2
+        // and stretches both.  They are chained (the resolve of one still overlaps the trace of the next).
+        // Smaller launches (one frame per call; a GPU's share of the frame under row sharding) end in a ~0.1 ms
+        // tail of a few long tasks and overlap freely to hide it.
+        if (g.opt_pipeline && (uint64_t)w.n_items * n >= Context::CHAIN_MIN_PATHS && g.prev_traced)
             HIP_TRY(hipStreamWaitEvent(ts, g.prev_traced, 0));
         int slot = -1;
         if (g.opt_timing) {

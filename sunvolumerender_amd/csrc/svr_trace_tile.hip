@@ -167,33 +167,41 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
     Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // Work distribution.  A single returning atomic saturates near 88 dequeues/us chip-wide
-    // (MI355X_MICROARCH.md "dequeue"), which capped this kernel at 0.19 ms per 1024^2 frame.  So: tasks are
-    // handed out in units of w.unit consecutive tasks (tile-major: the frames of one tile), from
-    // TICKET_SHARDS counters, each owning a contiguous range of units (an image band).  Blocks start on the
-    // shard blockIdx % 8 -- blocks b and b+8 share an XCD, so a band's bricks stay in that XCD's L2 -- and
-    // move on to the other shards when theirs is drained (placement affects speed only, never results).
+    // (MI355X_MICROARCH.md "dequeue"), which capped this kernel at 0.19 ms per 1024^2 frame.  So tasks are handed
+    // out (in units of w.unit consecutive tasks) from TICKET_SHARDS counters; counter j owns the units j, j + 8,
+    // j + 16 ... of ONE global order, and a block starts on counter blockIdx % 8 and moves on when that is drained.
+    // The global order runs over the tile rows from the image centre outwards: the expensive tiles (the object is
+    // where the camera looks) are started first and the launch ends on cheap, mostly skipped ones, instead of
+    // waiting for a few long tasks -- the tail was 0.15 ms of every launch, a fifth of a launch on one eighth of
+    // the image.  (Placement affects speed only, never results.)
     const uint32_t unit = w.unit;
     const uint32_t n_units = (n_tasks + unit - 1u) / unit;
-    const uint32_t per_shard = (n_units + TICKET_SHARDS - 1u) / TICKET_SHARDS;
     const uint32_t shard0 = blockIdx.x % TICKET_SHARDS;
+    const uint32_t row_tasks = tiles_x * fgroups;                 // tasks of one tile row
+    const uint32_t c_row = tiles_y >> 1;
 
     for (uint32_t si = 0; si < TICKET_SHARDS; ++si) {
         const uint32_t shard = (shard0 + si) % TICKET_SHARDS;
-        const uint32_t u_begin = shard * per_shard;
-        const uint32_t u_count = u_begin >= n_units ? 0u : min(per_shard, n_units - u_begin);
         uint32_t* ticket = w.ticket + shard * TICKET_STRIDE;
         for (;;) {
+            // away from the home counter, look before taking: when the launch runs out, every wave visits every
+            // counter once, and 4096 x 8 returning atomics alone took ~45 us (a plain load of a drained counter
+            // is free; the counters only grow, so a stale value just means one atomic more)
+            if (si != 0u && __atomic_load_n(ticket, __ATOMIC_RELAXED) * TICKET_SHARDS + shard >= n_units) break;
             uint32_t u = 0;
             if (lane == 0) u = atomicAdd(ticket, 1u);
             u = __builtin_amdgcn_readfirstlane(u);
-            if (u >= u_count) break;
-            const uint32_t t_begin = (u_begin + u) * unit;
+            const uint32_t unit_id = u * TICKET_SHARDS + shard;
+            if (unit_id >= n_units) break;
+            const uint32_t t_begin = unit_id * unit;
             const uint32_t t_end = min(t_begin + unit, n_tasks);
-            for (uint32_t task = t_begin; task < t_end; ++task) {
+            for (uint32_t k = t_begin; k < t_end; ++k) {
+                // k-th task of the centre-out order -> (tile row, tile column, frame group)
+                const uint32_t rr = k / row_tasks, in_row = k - rr * row_tasks;
+                const uint32_t off = (rr + 1u) >> 1;
+                const uint32_t ty = (rr & 1u) ? c_row - off : c_row + off;
                 if (COUNT) c.loops += (lane == 0);
-                uint32_t tile = task / fgroups;
-                uint32_t fg = task - tile * fgroups;
-                uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+                const uint32_t tx = in_row / fgroups, fg = in_row - tx * fgroups;
                 uint32_t pl = lane & ((1u << P2) - 1u);
                 uint32_t slot = (fg << fl2) + (lane >> P2);
                 uint32_t px = (tx << tw2) + (pl & ((1u << tw2) - 1u));
