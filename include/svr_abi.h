@@ -196,6 +196,7 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
 #define SVR_OPT_RAY_SKIP 10        /* 1 (default): per-ray conservative march over the dilated empty mask: a walk that can
                                      never meet a non-transparent macro-cell ends at once when no random draw follows it,
                                      and other walks skip cell tests up to their first possibly-occupied cell (bit-identical) */
+#define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */
 #define SVR_OPT_REFILL_MIN_IDLE 8 /* persistent kernel: regenerate lanes once this many of a wave's 64 lanes are idle

@@ -134,6 +134,7 @@ LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_BRICK = 0, 1, 2
 OPT_ENV_ON_ESCAPE, OPT_KERNEL, OPT_COUNT, OPT_TIMING, OPT_SKIP_TONEMAP, OPT_BLOCKS_PER_CU = 1, 2, 3, 4, 5, 6
 OPT_PIPELINE, OPT_REFILL_MIN_IDLE, OPT_EMPTY_SKIP, OPT_RAY_SKIP, OPT_FRAMES_PER_WAVE_LOG2 = 7, 8, 9, 10, 11
 OPT_RAYCAST_LANES_LOG2 = 12
+OPT_FRAME_AHEAD = 13
 KERNEL_AUTO, KERNEL_PIXEL, KERNEL_TILE, KERNEL_ULOOP, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4
 
 ELEM_I8, ELEM_U8, ELEM_I16, ELEM_U16, ELEM_I32, ELEM_U32, ELEM_F32, ELEM_F64 = range(8)

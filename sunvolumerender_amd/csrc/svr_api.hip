@@ -77,6 +77,17 @@ struct Context {
     unsigned long long* d_counters = nullptr;
     uint32_t* d_ticket = nullptr;
     hipEvent_t prev_traced = nullptr;   // `traced` event of the latest trace launch (owned by its set)
+    // frames traced ahead of the host's render_pathtracer calls (render_frames)
+    struct Ahead {
+        bool valid = false;
+        svr::DevScene scene;
+        svr::DevWork shape;             // window / shard of the launch
+        uint64_t content = 0;
+        uint32_t first = 0, count = 0, depth = 0;
+        int set = -1;
+    } ahead[2];                         // the batch being consumed and the one traced while it is consumed
+    uint64_t content_version = 0;       // bumped whenever texture contents or handles change
+    int opt_frame_ahead = 1;
     // Frame pipelining: a render call is cut into groups of <= GROUP frames; each group is traced on
     // one of NSETS internal streams into that set's scratch slots and resolved (running mean + tone map)
     // on the caller's stream, so the trace kernels of consecutive frames/calls overlap on the GPU while
@@ -402,6 +413,7 @@ int ensure_slots(uint32_t W, uint32_t H, uint32_t nslots)
     size_t need = (size_t)3 * W * H;
     if (g.slot_floats == need && g.slots_per_set >= nslots) return 0;
     HIP_TRY(hipDeviceSynchronize());
+    g.ahead[0].valid = g.ahead[1].valid = false;
     for (auto& st : g.sets) {
         if (st.lbuf) { HIP_TRY(hipFree(st.lbuf)); st.lbuf = nullptr; }
         st.used = false;
@@ -453,30 +465,29 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     cfg.blocks_per_cu = g.opt_blocks_per_cu > 0 ? g.opt_blocks_per_cu : 4;
     cfg.frames_log2 = g.opt_frames_log2;
     cfg.unit_override = g.opt_unit;
-    for (uint32_t g0 = 0; g0 < nframes; g0 += Context::GROUP) {
-        uint32_t n = nframes - g0 < (uint32_t)Context::GROUP ? nframes - g0 : (uint32_t)Context::GROUP;
-        bool last = g0 + n >= nframes;
-        int si = g.next_set;
-        g.next_set = (g.next_set + 1) % Context::NSETS;
+    // one trace launch of n_trace frames starting at frame `first` into scratch set `si`, then the resolve of its
+    // first n_resolve frames
+    auto trace_group = [&](int si, uint32_t first, uint32_t n_trace, uint32_t n_resolve, bool want_img) -> int {
         Context::SlotSet& set = g.sets[si];
+        for (auto& a : g.ahead) if (a.valid && a.set == si) a.valid = false;     // its slots are about to be overwritten
         hipStream_t ts = g.opt_pipeline ? set.stream : g.stream;
         svr::DevWork w;
         fill_work(w, s.imageW, s.imageH);
         w.hdr = (float*)rp->hdrBuffer;
-        w.img = (tonemap && last && !g.opt_skip_tonemap) ? (uint8_t*)img : nullptr;
+        w.img = want_img ? (uint8_t*)img : nullptr;
         w.lbuf = set.lbuf;
         w.slot_stride = (uint32_t)g.slot_floats;
         w.ticket = g.d_ticket + (size_t)svr::TICKET_SHARDS * svr::TICKET_STRIDE * si;
         w.traceDepth = rp->traceDepth;
-        w.frame0 = rp->frameNo + g0;
-        w.nframes = n;
+        w.frame0 = first;
+        w.nframes = n_trace;
         // the scratch slots of this set are free again once their previous resolve has run
         if (g.opt_pipeline && set.used) HIP_TRY(hipStreamWaitEvent(ts, set.resolved, 0));
         // A large trace launch fills the chip by itself; running two of them at once only makes them share L2
         // and stretches both.  They are chained (the resolve of one still overlaps the trace of the next).
         // Smaller launches (one frame per call; a GPU's share of the frame under row sharding) end in a ~0.1 ms
         // tail of a few long tasks and overlap freely to hide it.
-        if (g.opt_pipeline && (uint64_t)w.n_items * n >= Context::CHAIN_MIN_PATHS && g.prev_traced)
+        if (g.opt_pipeline && (uint64_t)w.n_items * n_trace >= Context::CHAIN_MIN_PATHS && g.prev_traced)
             HIP_TRY(hipStreamWaitEvent(ts, g.prev_traced, 0));
         int slot = -1;
         if (g.opt_timing) {
@@ -498,9 +509,69 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
             g.prev_traced = set.traced;
             HIP_TRY(hipStreamWaitEvent(g.stream, set.traced, 0));
         }
-        HIP_TRY(svr::launch_resolve(s, w, g.stream));
-        if (g.opt_pipeline) HIP_TRY(hipEventRecord(set.resolved, g.stream));
+        if (n_resolve) {
+            w.nframes = n_resolve;
+            HIP_TRY(svr::launch_resolve(s, w, g.stream));
+            if (g.opt_pipeline) HIP_TRY(hipEventRecord(set.resolved, g.stream));
+        }
         set.used = true;
+        if (n_resolve < n_trace) {
+            // a free entry, else the older batch
+            Context::Ahead& a = !g.ahead[0].valid ? g.ahead[0] : (!g.ahead[1].valid ? g.ahead[1] : (g.ahead[0].first < g.ahead[1].first ? g.ahead[0] : g.ahead[1]));
+            a.valid = true; a.scene = s; a.shape = w; a.content = g.content_version;
+            a.first = first; a.count = n_trace; a.depth = rp->traceDepth; a.set = si;
+        }
+        return 0;
+    };
+    auto next_set = [&]() { int si = g.next_set; g.next_set = (g.next_set + 1) % Context::NSETS; return si; };
+    const bool want_img = tonemap && !g.opt_skip_tonemap;
+
+    // The reference's host calls render_pathtracer once per frame (gui/canvas.cpp:96).  A frame's radiance is a pure
+    // function of (scene, pixel, frame number), so frames can be traced AHEAD of the calls that ask for them: a
+    // 32-frame launch costs 0.13 ms per frame on c3, a 1-frame launch 0.23.  The batch doubles with the frame number
+    // (1, 2, 4 ... GROUP), so a host that restarts the render on every mouse event never traces more than twice what
+    // it shows.  Anything that could change a frame -- scene PODs, texture contents, window, shard, trace depth --
+    // invalidates the frames in stock.
+    if (nframes == 1 && g.opt_frame_ahead && g.opt_pipeline && !g.opt_count && !g.opt_debug_stop && cfg.kernel == svr::KERNEL_TILE) {
+        const uint32_t n = rp->frameNo;
+        svr::DevWork shape;
+        fill_work(shape, s.imageW, s.imageH);
+        auto in_stock = [&](const Context::Ahead& a, uint32_t frame) {
+            return a.valid && a.content == g.content_version && a.depth == rp->traceDepth && frame >= a.first && frame - a.first < a.count &&
+                   memcmp(&a.scene, &s, sizeof s) == 0 && a.shape.x0 == shape.x0 && a.shape.x1 == shape.x1 && a.shape.y0 == shape.y0 &&
+                   a.shape.y1 == shape.y1 && a.shape.strip_rows == shape.strip_rows && a.shape.rank == shape.rank && a.shape.world == shape.world;
+        };
+        for (Context::Ahead& a : g.ahead) {
+            if (!in_stock(a, n)) continue;
+            // in stock: fold slot n - first into the accumulator
+            Context::SlotSet& set = g.sets[a.set];
+            svr::DevWork w = shape;
+            w.hdr = (float*)rp->hdrBuffer;
+            w.img = want_img ? (uint8_t*)img : nullptr;
+            w.slot_stride = (uint32_t)g.slot_floats;
+            w.lbuf = set.lbuf + (size_t)(n - a.first) * g.slot_floats;
+            w.traceDepth = rp->traceDepth;
+            w.frame0 = n;
+            w.nframes = 1;
+            HIP_TRY(hipStreamWaitEvent(g.stream, set.traced, 0));
+            HIP_TRY(svr::launch_resolve(s, w, g.stream));
+            HIP_TRY(hipEventRecord(set.resolved, g.stream));
+            // steady state: half-way through a full batch, start tracing the next one so that it is ready in time
+            const uint32_t next_first = a.first + a.count;
+            if (a.count == (uint32_t)Context::GROUP && n - a.first >= a.count / 2u && !in_stock(g.ahead[0], next_first) && !in_stock(g.ahead[1], next_first))
+                return trace_group(next_set(), next_first, (uint32_t)Context::GROUP, 0, false);
+            return 0;
+        }
+        uint32_t batch = 1;
+        while (batch < (uint32_t)Context::GROUP && 2u * batch <= n + 1u) batch *= 2u;
+        if (batch > 1 && ensure_slots(s.imageW, s.imageH, (uint32_t)Context::GROUP)) return g.err_code;
+        return trace_group(next_set(), n, batch, 1, want_img);
+    }
+
+    for (uint32_t g0 = 0; g0 < nframes; g0 += Context::GROUP) {
+        uint32_t n = nframes - g0 < (uint32_t)Context::GROUP ? nframes - g0 : (uint32_t)Context::GROUP;
+        bool last = g0 + n >= nframes;
+        if (trace_group(next_set(), rp->frameNo + g0, n, n, want_img && last)) return g.err_code;
     }
     return 0;
 }
@@ -679,6 +750,7 @@ static int upload_zero_prefix(Texture* t)
     e = hipMemcpy(t->zero_prefix, pre.data(), pre.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail((int)e, "zero-prefix upload failed: %s", hipGetErrorName(e));
     t->version++;
+    g.content_version++;
     return 0;
 }
 
@@ -720,6 +792,7 @@ int svr_destroy_texture(uint64_t handle)
     t->magic = 0;
     delete t;
     g.textures.erase(it);
+    g.content_version++;
     return 0;
 }
 
@@ -870,6 +943,7 @@ int svr_set_option(int key, int value)
     case SVR_OPT_RAY_SKIP: g.opt_ray_skip = value ? 1 : 0; return 0;
     case 100: g.opt_debug_stop = value; return 0;      // undocumented timing ablation (wrong images)
     case 101: g.opt_unit = value; return 0;            // undocumented: tasks per ticket of the tile kernel
+    case SVR_OPT_FRAME_AHEAD: g.opt_frame_ahead = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_RAYCAST_LANES_LOG2:
         if (value < 0 || value > 5) return fail(-6, "SVR_OPT_RAYCAST_LANES_LOG2: bad value %d (0..5)", value);
         g.opt_rc_lanes = value; return 0;
@@ -898,6 +972,7 @@ int svr_get_option(int key)
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     case SVR_OPT_FRAMES_PER_WAVE_LOG2: return g.opt_frames_log2;
     case SVR_OPT_RAYCAST_LANES_LOG2: return g.opt_rc_lanes;
+    case SVR_OPT_FRAME_AHEAD: return g.opt_frame_ahead;
     default: return -1;
     }
 }

@@ -351,3 +351,38 @@ def test_frame_major_group_march(hip_dev, case, nframes):
             assert_bit_exact(hdr, ref_hdr, f"{case} {nframes} frames count={count}")
         if count:
             assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"]
+
+
+def test_frame_ahead_matches_per_frame_calls(hip_dev):
+    """render_pathtracer traces frames ahead of the calls that ask for them (batches 1, 2, 4 ... 32, the next batch
+    started half-way through the current one).  70 per-frame calls, a scene edit in between, the feature on and off:
+    always the oracle's accumulator, bit for bit."""
+    sc = scenes.make_scene("tiny_head", trace_depth=1)
+    ref70, ref_img70, _ = oracle_frames(sc, 70)
+    sc2 = dataclasses.replace(sc, density_scale=1.7)
+    ref45, _, _ = oracle_frames(sc2, 45)
+    for ahead in (1, 0):
+        canvas = host.Canvas(hip_dev, sc.width, sc.height)
+        try:
+            hip_dev.set_option(abi.OPT_FRAME_AHEAD, ahead)
+            scenes.apply_to_canvas(sc, canvas)
+            for f in range(70):
+                canvas.paint()
+            hip_dev.synchronize()
+            assert_bit_exact(canvas.read_hdr(), ref70, f"70 per-frame calls, frame-ahead {ahead}")
+            assert np.array_equal(canvas.read_img(), ref_img70)
+            # an edit restarts the render: frames in stock for the old scene must not be used
+            canvas.SetDensityScale(1.7)
+            for f in range(45):
+                canvas.paint()
+            hip_dev.synchronize()
+            assert_bit_exact(canvas.read_hdr(), ref45, f"45 calls after an edit, frame-ahead {ahead}")
+            # back to the first scene, continuing from a frame number that is not a batch start
+            canvas.SetDensityScale(1.0)
+            for f in range(70):
+                canvas.paint()
+            hip_dev.synchronize()
+            assert_bit_exact(canvas.read_hdr(), ref70, "70 calls after a second edit")
+        finally:
+            hip_dev.set_option(abi.OPT_FRAME_AHEAD, 1)
+            canvas.close()
