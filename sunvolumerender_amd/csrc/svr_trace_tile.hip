@@ -1,23 +1,24 @@
 // svr_trace_tile.hip -- the default path-tracing kernel for gfx950.
 //
-// Shape (what the rocprof counters of the earlier kernels asked for):
-//  * persistent waves pull (8x8 pixel tile, frame) tasks from one ticket; tasks are tile-major, so the
-//    waves resident at any moment march through neighbouring tubes of the volume, and the 64 rays of a
-//    wave start together and stay within a few dozen voxels of depth of each other (Woodcock steps have
-//    mean 1/sigma_max): the 256-B bricks they touch are served by the vector L1 / per-XCD L2
-//    (measured 90 % / 93 % hit), not by HBM;
-//  * the transfer-function alpha LUT (the only table the Woodcock loop needs) and an empty-space
-//    bitmask live in LDS;
-//  * EMPTY-SPACE SKIPPING, bit-exact: a Woodcock iteration whose trilinear cell lies in a macro-cell
-//    where the transfer function's alpha is exactly 0 for every reachable intensity has sigma_t == 0,
-//    so the reference's accept test `xi < sigma_t / sigma_max` (woodcock_tracking.h:43) fails whatever
-//    the fetch returns; the 8 voxel loads, the filter and the LUT read are skipped while both random
-//    draws of the iteration are still consumed, so every path follows the reference's RNG stream and
-//    produces the same bits.  ~90 % of the Woodcock iterations of a CT-like scene are in air;
-//  * the scatter point's intensity is the last Woodcock fetch (same position, same arithmetic), not a
-//    second fetch;
-//  * voxel addresses are 32-bit byte offsets from a scalar base (saddr global loads), brick strides use
-//    24-bit multiplies.
+// Shape (what the rocprof counters of the earlier kernels asked for; DESIGN.md 5.1 has the measurements):
+//  * persistent 1024-thread blocks, one per CU; a wave pulls one task = (64 >> f) pixels x (1 << f) frames of a
+//    launch group from sharded tickets.  With many frames per launch the lanes of a wave are the same two pixels in
+//    32 different frames: they start in the same voxels, share their whole-ray test (svr_walk.hpp,
+//    first_occupied_group) and stay within a few dozen voxels of depth of each other, so the 256-B bricks they touch
+//    come from the vector L1 / L2, not from HBM;
+//  * the transfer-function alpha LUT (the only table the Woodcock loop needs), the `empty` and `deep-empty`
+//    macro-cell bitmasks and a half-resolution distance field live in LDS (84 KB);
+//  * EMPTY-SPACE SKIPPING, bit-exact: a Woodcock iteration whose trilinear cell lies in a macro-cell where the
+//    transfer function's alpha is exactly 0 for every reachable intensity has sigma_t == 0, so the reference's
+//    accept test `xi < sigma_t / sigma_max` (woodcock_tracking.h:43) fails whatever the fetch returns; the 8 voxel
+//    loads, the filter and the LUT read are skipped while both random draws of the iteration are still consumed, so
+//    every path follows the reference's RNG stream and produces the same bits.  Whole rays and stretches of rays
+//    that cannot collide are found by sphere tracing on the distance field (svr_walk.hpp) and never iterate at all
+//    when no random draw follows them.  On c3, 68 % of the reference's Woodcock iterations never run and 95 % of its
+//    taps are never fetched;
+//  * the scatter point's intensity is the last Woodcock fetch (same position, same arithmetic), not a second fetch;
+//  * voxel addresses are 32-bit byte offsets from a scalar base (saddr global loads), brick strides use 24-bit
+//    multiplies.
 // Radiance goes to the scratch slots; k_resolve (svr_kernels.hip) folds it into the running mean.
 #include "svr_walk.hpp"
 
