@@ -16,19 +16,110 @@
 // of the wave has a contributing sample pending (or has finished).  Transfer-function colours are
 // assumed finite (0 * inf would differ).
 //
-// Persistent 512-thread blocks pull tasks (64 >> SL2 pixels each) from sharded tickets, as k_trace_tile.
+// Long empty stretches are not stepped through at all: a sphere trace on the distance field (svr_walk.hpp) tells how far
+// the ray is clear, and the sample chain is replayed in closed form up to there (chain_* below).
+//
+// Persistent 1024-thread blocks pull tasks (64 >> SL2 pixels each) from sharded tickets, as k_trace_tile.
 #include "svr_walk.hpp"
 
 namespace svr {
 
-#define SVR_RC_THREADS 512
+#define SVR_RC_THREADS 1024    // 16 waves share the RGBA table, the two bitmasks and the distance field (96 KB): one block per CU
 
 struct LdsRaycast {
     float4 rgba[SVR_TF_MAX + SVR_TF_PAD];      // entry e = texel clamp(e-1)
-    uint32_t dist[1];
-    uint32_t mask[1];
+    uint32_t dist[DIST_WORDS_MAX];             // svr_walk.hpp: distance field, deep-empty bits, empty bits
+    uint32_t mask[MASK_WORDS_MAX];
     uint32_t emask[MASK_WORDS_MAX];
 };
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The reference's sample parameters are a float accumulation chain t_{n+1} = fl(t_n + h) (raycasting.cu:63).  To skip
+// samples without evaluating them the chain has to be replayed exactly.  Within one binade [2^e, 2^(e+1)) every t is
+// a multiple of u = ulp, and fl(t + h) = t + delta with ONE delta for the whole binade (h = q u + r rounds to q u or
+// (q + 1) u, the same way for every t, unless r is exactly u / 2 where ties-to-even alternates).  So k steps inside a
+// binade are t + k * delta, computed on the integer mantissas; the step that crosses into the next binade is taken
+// with a real float addition.  Chains the closed form does not cover (t < 1, a tie, delta == 0) are simply not
+// skipped: the caller falls back to one chunk at a time.
+// ------------------------------------------------------------------------------------------------------------------
+struct ChainSeg { uint32_t A, J, kmax; float u; bool ok; };     // t = A u, delta = J u, steps k <= kmax stay in the binade
+
+SVR_DEV ChainSeg chain_segment(float t, float h)
+{
+    ChainSeg g;
+    const uint32_t tb = __float_as_uint(t);
+    const uint32_t ex = tb >> 23;                                   // t >= 1: sign 0, exponent >= 127
+    g.u = __uint_as_float((ex - 23u) << 23);
+    g.A = (tb & 0x7fffffu) | 0x800000u;
+    const float t1 = t + h;
+    const float delta = t1 - t;                                     // exact
+    const float err = h - delta;                                    // exact: the rounding error of t + h
+    const bool same = (__float_as_uint(t1) >> 23) == ex;
+    g.J = (uint32_t)(delta * __uint_as_float((127u + 127u + 23u - ex) << 23));        // delta / u, an integer < 2^24
+    g.ok = same && delta > 0.f && __builtin_fabsf(err) != 0.5f * g.u && t >= 1.f && ex < 127u + 100u;
+    g.kmax = g.ok ? (0xffffffu - g.A) / g.J : 0u;
+    return g;
+}
+
+// number of chain elements t^[0] = t, t^[1], ... that are < bound (inclusive: <= bound); cap = false if the chain left
+// the closed form before the answer was known (then the count is a lower bound that is still safe to skip)
+SVR_DEV uint32_t chain_count(float t, float h, float bound, bool inclusive, bool& exact)
+{
+    uint32_t n = 0;
+    exact = true;
+    for (int seg = 0; seg < 6; ++seg) {
+        if (!(inclusive ? t <= bound : t < bound)) return n;
+        const ChainSeg g = chain_segment(t, h);
+        if (!g.ok) {
+            // one real step (binade crossing) -- or give up on anything the closed form does not cover
+            const float t1 = t + h;
+            if (!(t1 > t) || !(t >= 1.f)) { exact = false; return n; }
+            n += 1u; t = t1;
+            continue;
+        }
+        // elements t + k delta, k = 0 .. kmax, of this binade that are before the bound
+        const float xs = bound * __uint_as_float((254u - (__float_as_uint(g.u) >> 23)) << 23);      // bound / u (exact scaling)
+        uint32_t k_in;
+        if (xs >= 16777216.f) k_in = g.kmax + 1u;                  // the bound lies beyond this binade
+        else {
+            const float fl = __builtin_floorf(xs);
+            uint32_t X = (uint32_t)fl;                               // t is before the bound, so X >= A >= 2^23
+            if (!inclusive && fl == xs) X -= 1u;                   // strict: A + k J <= ceil(x) - 1
+            k_in = X >= g.A ? (X - g.A) / g.J + 1u : 0u;
+            if (k_in > g.kmax + 1u) k_in = g.kmax + 1u;
+        }
+        n += k_in;
+        if (k_in <= g.kmax) return n;                              // the bound was met inside the binade
+        // all kmax + 1 elements counted: continue from the first element of the next binade
+        t = (float)(g.A + g.kmax * g.J) * g.u;
+        t = t + h;
+    }
+    exact = false;
+    return n;
+}
+
+// t after n chain steps; ok = false if the closed form gave up (t is then unchanged)
+SVR_DEV float chain_advance(float t, float h, uint32_t n, bool& ok)
+{
+    const float t_in = t;
+    ok = true;
+    for (int seg = 0; seg < 8 && n != 0u; ++seg) {
+        const ChainSeg g = chain_segment(t, h);
+        if (!g.ok) {
+            const float t1 = t + h;
+            if (!(t1 > t) || !(t >= 1.f)) { ok = false; return t_in; }
+            t = t1; n -= 1u;
+            continue;
+        }
+        const uint32_t k = n < g.kmax ? n : g.kmax;
+        t = (float)(g.A + k * g.J) * g.u;                          // exact: an integer below 2^24 times a power of two
+        n -= k;
+        if (n != 0u) { t = t + h; n -= 1u; }                       // the crossing step
+    }
+    if (n != 0u) { ok = false; return t_in; }
+    return t;
+}
 
 template <int LAYOUT, bool COUNT, bool SKIP, int SL2>
 __global__ __launch_bounds__(SVR_RC_THREADS) void k_raycast(const DevScene s, const DevWork w, float stepSize)
@@ -48,6 +139,12 @@ __global__ __launch_bounds__(SVR_RC_THREADS) void k_raycast(const DevScene s, co
             const uint4* src = reinterpret_cast<const uint4*>(s.empty_mask + DIST_WORDS_MAX + MASK_WORDS_MAX);
             uint4* dst = reinterpret_cast<uint4*>(L.emask);
             for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += SVR_RC_THREADS) dst[q] = src[q];
+            const uint4* src1 = reinterpret_cast<const uint4*>(s.empty_mask + DIST_WORDS_MAX);
+            uint4* dst1 = reinterpret_cast<uint4*>(L.mask);
+            for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += SVR_RC_THREADS) dst1[q] = src1[q];
+            const uint4* src0 = reinterpret_cast<const uint4*>(s.empty_mask);
+            uint4* dst0 = reinterpret_cast<uint4*>(L.dist);
+            for (uint32_t q = threadIdx.x; q < (s.dist_words + 3u) / 4u; q += SVR_RC_THREADS) dst0[q] = src0[q];
         }
         __syncthreads();
     }
@@ -94,6 +191,9 @@ __global__ __launch_bounds__(SVR_RC_THREADS) void k_raycast(const DevScene s, co
 #pragma unroll
             for (uint32_t i = 0; i + 1u < S; ++i) t = (i < j) ? t + h : t;
             uint32_t gv = 0, gc = 0;             // valid / contributing lanes of this ray's current chunk
+            // jumps need the whole box inside the texture domain (s.ray_skip) and sample points that cannot coincide
+            // with the eye (t >= 1 with |orig| < 2^20: dir * t is never absorbed)
+            const bool jump_ok = SKIP && s.ray_skip && fmax_(__builtin_fabsf(orig.x), fmax_(__builtin_fabsf(orig.y), __builtin_fabsf(orig.z))) < 1048576.f;
             v3 p = orig;
             int e = 0;
             float a = 0.f, alpha = 0.f;
@@ -104,13 +204,14 @@ __global__ __launch_bounds__(SVR_RC_THREADS) void k_raycast(const DevScene s, co
                     const bool need = !done && gc == 0u;
                     if (__ballot(need) == 0ull) break;
                     const bool valid = need && t <= tFar;
-                    bool contrib = false;
+                    bool contrib = false, deep = false;
                     if (valid) {
                         v3 q = orig + dir * t;
                         Cell c = cell_of(s, q);
                         v3 toCam = cam - q;
                         // the head-light direction must stay finite for "opacity 0 => contributes +0"
                         const bool finite = dot(toCam, toCam) >= 1e-30f;
+                        if (SKIP && jump_ok) deep = finite && cell_is_empty<true>(L, s, c);
                         if (!(SKIP && finite && cell_is_empty<false>(L, s, c))) {
                             if (COUNT) n_fetched++;
                             float intensity = tex_fetch<LAYOUT>(s, c) * s.densityScale;
@@ -123,7 +224,7 @@ __global__ __launch_bounds__(SVR_RC_THREADS) void k_raycast(const DevScene s, co
                             }
                         }
                     }
-                    const uint64_t vb = __ballot(valid), cb = __ballot(contrib);
+                    const uint64_t vb = __ballot(valid), cb = __ballot(contrib), db = __ballot(deep);
                     if (need) {
                         gv = (uint32_t)(vb >> gshift) & GMASK;
                         gc = (uint32_t)(cb >> gshift) & GMASK;
@@ -133,6 +234,36 @@ __global__ __launch_bounds__(SVR_RC_THREADS) void k_raycast(const DevScene s, co
                             if (nv < S) done = true;
 #pragma unroll
                             for (uint32_t i = 0; i < S; ++i) t += h;
+                            // the whole chunk sat in deep-empty cells: look ahead and replay the chain up to there
+                            if (SKIP && !done && (((uint32_t)(db >> gshift) & GMASK) == GMASK)) {
+                                const float t0 = __shfl(t, (int)gshift, 64);             // the chunk's first sample
+                                if (t0 >= 1.f && t0 <= tFar) {
+                                    const float t_clear = first_occupied(s, L, orig, dir, t0, tFar);
+                                    const bool to_end = t_clear == u2f(SVR_INF_BITS);
+                                    bool exact;
+                                    const uint32_t cnt = chain_count(t, h, to_end ? tFar : t_clear, to_end, exact);
+                                    uint32_t mine = (cnt + S - 1u) >> SL2;                // samples of this lane before the bound
+                                    uint32_t lo = mine, sum = mine;
+                                    bool all_exact = exact;
+#pragma unroll
+                                    for (uint32_t o = 1u; o < S; o <<= 1) {
+                                        lo = min(lo, (uint32_t)__shfl_xor((int)lo, (int)o, 64));
+                                        sum += (uint32_t)__shfl_xor((int)sum, (int)o, 64);
+                                        all_exact = all_exact && (__shfl_xor((int)all_exact, (int)o, 64) != 0);
+                                    }
+                                    if (to_end && all_exact) {
+                                        steps += sum;                                     // every remaining sample is transparent
+                                        done = true;
+                                    } else if (lo != 0u) {
+                                        bool ok;
+                                        const float tn = chain_advance(t, h, lo << SL2, ok);
+                                        bool all_ok = ok;
+#pragma unroll
+                                        for (uint32_t o = 1u; o < S; o <<= 1) all_ok = all_ok && (__shfl_xor((int)all_ok, (int)o, 64) != 0);
+                                        if (all_ok) { t = tn; steps += lo << SL2; }
+                                    }
+                                }
+                            }
                         }
                     }
                 }
@@ -234,7 +365,7 @@ hipError_t launch_raycast(const DevScene& s, const DevWork& w, float stepSize, b
     if (w.x1 == w.x0 || w.n_rows == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(w.ticket, 0, sizeof(uint32_t) * TICKET_SHARDS * TICKET_STRIDE, st);
     if (e != hipSuccess) return e;
-    const uint32_t max_blocks = (uint32_t)num_cus * 2u;                  // 2 x 8 waves per CU (48 KB LDS each)
+    const uint32_t max_blocks = (uint32_t)num_cus;                       // one 1024-thread block (16 waves, 96 KB LDS) per CU
     const bool skip = s.empty_mask != nullptr;
     if (s.layout == LAYOUT_LINEAR) {
         if (count) { if (skip) launch_s<LAYOUT_LINEAR, true, true>(s, w, stepSize, lanes_log2, max_blocks, st); else launch_s<LAYOUT_LINEAR, true, false>(s, w, stepSize, lanes_log2, max_blocks, st); }
