@@ -386,3 +386,35 @@ def test_frame_ahead_matches_per_frame_calls(hip_dev):
         finally:
             hip_dev.set_option(abi.OPT_FRAME_AHEAD, 1)
             canvas.close()
+
+
+@pytest.mark.parametrize("eye", [30.0, 47.9, 130.0, 1000.0, 4100.0, 70000.0])
+def test_raycasting_sample_chain_replay(hip_dev, eye):
+    """The ray caster replays the float chain t += h in closed form to skip transparent stretches.  Eye distances
+    put the samples in one binade, across one or across many binade boundaries (more than the closed form follows),
+    step sizes include exact rounding ties (h = 0.5 with t on odd multiples of the ulp), steps far below and far
+    above one voxel: image and step count are always the oracle's."""
+    sc0 = scenes.make_scene("tiny_head")
+    fov = 45.0 if eye < 500 else (4.0 if eye < 10000 else 0.25)
+    cam = host.camera_setup((0.3 * eye, -0.2 * eye, eye), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), fov, 0.0, 1.0, 1.0, sc0.width, sc0.height)
+    sc = dataclasses.replace(sc0, camera=cam)
+    orc = binding.OracleScene(sc)
+    canvas = host.Canvas(hip_dev, sc.width, sc.height)
+    try:
+        scenes.apply_to_canvas(sc, canvas)
+        canvas.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING)
+        # 1 + 2^-7 and 1 + 2^-11: h = 0.5 + half an ulp of t around 70000 / 4100 -> every addition is a rounding tie
+        for step in (None, 1.0, 0.0625, 5.0, 1.0 + 2.0 ** -22, 1.0 + 2.0 ** -7, 1.0 + 2.0 ** -11, 3.0e-3 if eye < 200 else 0.37):
+            st = sc.step_size() if step is None else step
+            ref, rc = orc.render_raycasting(step_size=st)
+            canvas.stepSize = st
+            hip_dev.set_option(abi.OPT_COUNT, 1)
+            hip_dev.reset_counters()
+            canvas.paint(sync=True)
+            cnt = hip_dev.counters()
+            hip_dev.set_option(abi.OPT_COUNT, 0)
+            assert cnt["raycast_steps"] == rc["raycast_steps"], (eye, st)
+            assert np.array_equal(canvas.read_img(), ref), (eye, st)
+    finally:
+        hip_dev.set_option(abi.OPT_COUNT, 0)
+        canvas.close()
