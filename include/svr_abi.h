@@ -225,6 +225,8 @@ typedef struct svr_counters {
     uint64_t iters_prefix_skipped; /* iterations before a walk's first possibly-occupied macro-cell (no cell test) */
     uint64_t reserved;
 } svr_counters;
+/* test hook: the ray caster's sample-chain replay on n items (t, h, bound, steps) -> (count <, count <=, t after steps, flags) */
+int svr_selftest_chain(const float* items, float* results, uint32_t n);
 int svr_get_counters(svr_counters* out);              /* synchronises the launch stream */
 int svr_reset_counters(void);
 

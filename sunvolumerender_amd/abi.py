@@ -194,6 +194,7 @@ PROTOTYPES = {
     "svr_get_option": (C.c_int, [C.c_int]),
     "svr_render_pathtracer_frames": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_uint32]),
     "svr_hdr_to_ldr": (C.c_int, [C.c_void_p, _P(RenderParams)]),
+    "svr_selftest_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "svr_get_counters": (C.c_int, [_P(Counters)]),
     "svr_reset_counters": (C.c_int, []),
     "svr_get_kernel_time": (C.c_int, [_P(C.c_double), _P(C.c_uint64)]),

@@ -977,6 +977,22 @@ int svr_get_option(int key)
     }
 }
 
+// test hook (not part of the rendering API): runs the ray caster's chain primitives on n items of (t, h, bound, steps)
+int svr_selftest_chain(const float* items, float* results, uint32_t n)
+{
+    if (ensure_init()) return g.err_code;
+    if (!items || !results || n == 0) return fail(-4, "svr_selftest_chain: bad arguments");
+    float4 *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, (size_t)n * 16));
+    HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * 16));
+    HIP_TRY(hipMemcpy(d_in, items, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(svr::launch_chain_selftest(d_in, d_out, n, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpy(results, d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
+    hipFree(d_in); hipFree(d_out);
+    return 0;
+}
+
 int svr_get_counters(svr_counters* out)
 {
     if (ensure_init()) return g.err_code;

@@ -47,6 +47,8 @@ hipError_t launch_empty_mask(const uint16_t* mm, int gx, int gy, int gz, const u
                              float densityScale, uint32_t* mask, uint32_t mask_words, uint8_t* tmp, hipStream_t stream);
 // hdr_to_ldr over the owned pixels
 hipError_t launch_tonemap(const DevScene& scene, const DevWork& work, hipStream_t stream);
+// self-test of the ray caster's sample-chain replay (tests only): in = (t, h, bound, n) per item
+hipError_t launch_chain_selftest(const float4* in, float4* out, uint32_t n, hipStream_t stream);
 // kernel_raycasting over the owned pixels
 hipError_t launch_raycast(const DevScene& scene, const DevWork& work, float stepSize, bool count, int num_cus, int lanes_log2, hipStream_t stream);
 // repack a [nz][ny][nx] u16 volume (device) into the padded LINEAR or BRICK layout (device)

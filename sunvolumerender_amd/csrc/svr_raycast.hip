@@ -244,23 +244,23 @@ __global__ __launch_bounds__(SVR_RC_THREADS) void k_raycast(const DevScene s, co
                                     const uint32_t cnt = chain_count(t, h, to_end ? tFar : t_clear, to_end, exact);
                                     uint32_t mine = (cnt + S - 1u) >> SL2;                // samples of this lane before the bound
                                     uint32_t lo = mine, sum = mine;
-                                    bool all_exact = exact;
+                                    int all_exact = exact ? 1 : 0;          // (no &&: every lane must take part in every shuffle)
 #pragma unroll
                                     for (uint32_t o = 1u; o < S; o <<= 1) {
                                         lo = min(lo, (uint32_t)__shfl_xor((int)lo, (int)o, 64));
                                         sum += (uint32_t)__shfl_xor((int)sum, (int)o, 64);
-                                        all_exact = all_exact && (__shfl_xor((int)all_exact, (int)o, 64) != 0);
+                                        all_exact &= __shfl_xor(all_exact, (int)o, 64);
                                     }
-                                    if (to_end && all_exact) {
+                                    if (to_end && all_exact != 0) {
                                         steps += sum;                                     // every remaining sample is transparent
                                         done = true;
                                     } else if (lo != 0u) {
                                         bool ok;
                                         const float tn = chain_advance(t, h, lo << SL2, ok);
-                                        bool all_ok = ok;
+                                        int all_ok = ok ? 1 : 0;
 #pragma unroll
-                                        for (uint32_t o = 1u; o < S; o <<= 1) all_ok = all_ok && (__shfl_xor((int)all_ok, (int)o, 64) != 0);
-                                        if (all_ok) { t = tn; steps += lo << SL2; }
+                                        for (uint32_t o = 1u; o < S; o <<= 1) all_ok &= __shfl_xor(all_ok, (int)o, 64);
+                                        if (all_ok != 0) { t = tn; steps += lo << SL2; }
                                     }
                                 }
                             }
@@ -336,6 +336,25 @@ __global__ __launch_bounds__(SVR_RC_THREADS) void k_raycast(const DevScene s, co
             atomicAdd(&w.counters[CNT_TAPS_EXEC], ex);
         }
     }
+}
+
+// unit-test hook for the chain primitives: item i = (t, h, bound, n) -> (count strict, count inclusive, exact flags, advanced t, ok)
+__global__ void k_chain_selftest(const float4* __restrict__ in, float4* __restrict__ out, uint32_t n_items)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const float4 q = in[i];
+    bool e0, e1, ok;
+    const uint32_t c0 = chain_count(q.x, q.y, q.z, false, e0);
+    const uint32_t c1 = chain_count(q.x, q.y, q.z, true, e1);
+    const float ta = chain_advance(q.x, q.y, (uint32_t)q.w, ok);
+    out[i] = make_float4(__uint_as_float(c0), __uint_as_float(c1), ta, __uint_as_float((e0 ? 1u : 0u) | (e1 ? 2u : 0u) | (ok ? 4u : 0u)));
+}
+
+hipError_t launch_chain_selftest(const float4* in, float4* out, uint32_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_chain_selftest, dim3((n + 255u) / 256u), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
 }
 
 template <int LAYOUT, bool COUNT, bool SKIP>

@@ -418,3 +418,42 @@ def test_raycasting_sample_chain_replay(hip_dev, eye):
     finally:
         hip_dev.set_option(abi.OPT_COUNT, 0)
         canvas.close()
+
+
+def test_sample_chain_primitives(hip_dev):
+    """chain_count / chain_advance of svr_raycast.hip (closed-form replay of t += h) against the brute-force float32
+    loop: counts are exact when flagged exact and never too large otherwise; advanced values are the chain's."""
+    import random
+    f = np.float32
+    random.seed(5)
+    items = []
+    for _ in range(4000):
+        t = random.choice([random.uniform(1, 9000), random.uniform(1, 9000), 2.0 ** random.randint(0, 20) - random.uniform(0, 3)])
+        t = max(t, 1.0)
+        h = random.choice([0.5, 0.43301, 0.5002441, 0.50390625, 0.03125, 2.5, 0.0015, 0.185, random.uniform(0.001, 3)])
+        bound = t + random.uniform(0, 200) * h * random.choice([1, 1, 10])
+        items.append((t, h, bound, float(random.randint(0, 3000))))
+    a = np.array(items, dtype=np.float32)
+    out = np.zeros_like(a)
+    hip_dev.check(hip_dev.lib.svr_selftest_chain(a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), len(a)))
+    u = out.view(np.uint32)
+    n_exact = 0
+    for i in range(len(a)):
+        t, h, bound, n = a[i]
+        c0 = c1 = 0
+        x = f(t)
+        while x < bound and c0 < 10 ** 6:
+            c0 += 1; x = f(x + h)
+        x = f(t)
+        while x <= bound and c1 < 10 ** 6:
+            c1 += 1; x = f(x + h)
+        x = f(t)
+        for _ in range(int(n)):
+            x = f(x + h)
+        g0, g1, ta, fl = int(u[i, 0]), int(u[i, 1]), out[i, 2], int(u[i, 3])
+        assert (g0 == c0) if fl & 1 else (g0 <= c0), (a[i], g0, c0)
+        assert (g1 == c1) if fl & 2 else (g1 <= c1), (a[i], g1, c1)
+        if fl & 4:
+            assert ta == x, (a[i], ta, x)
+        n_exact += bool(fl & 1) + bool(fl & 2) + bool(fl & 4)
+    assert n_exact > 2 * len(a)          # the closed form covers most chains
