@@ -90,7 +90,19 @@ def cpu_baseline(scene, trace_depth, budget_s):
                   f"(every 128 rows) of the {W}x{H} frame = {band_px * frames} paths in {dt:.1f} s",
         "raycasting_mpix_s": round(rc_px / rc_dt / 1e6, 5),
         "raycasting_sample": f"oracle ray caster, {rc_px} pixels (8-row bands every 128 rows) in {rc_dt:.1f} s",
+        "host_cores": os.cpu_count(),
+        "cpu_model": _cpu_model(),
     }
+
+
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -235,6 +247,9 @@ def main():
             try:
                 roof["traffic"] = json.loads(tfile.read_text())["traffic_bytes_per_launch"]
                 roof["traffic_source"] = str(tfile.relative_to(ROOT))
+                if roof.get("kernel_avg_ms"):
+                    # the same fraction on the bytes HBM really moved ("quote the fraction both ways")
+                    roof["frac_traffic"] = round(roof["traffic"] / (roof["kernel_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             except Exception:
                 pass
         out = {
