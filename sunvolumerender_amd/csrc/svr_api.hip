@@ -982,14 +982,14 @@ int svr_selftest_chain(const float* items, float* results, uint32_t n)
 {
     if (ensure_init()) return g.err_code;
     if (!items || !results || n == 0) return fail(-4, "svr_selftest_chain: bad arguments");
-    float4 *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_in, (size_t)n * 16));
-    HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * 16));
-    HIP_TRY(hipMemcpy(d_in, items, (size_t)n * 16, hipMemcpyHostToDevice));
-    HIP_TRY(svr::launch_chain_selftest(d_in, d_out, n, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    HIP_TRY(hipMemcpy(results, d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
-    hipFree(d_in); hipFree(d_out);
+    float4* d_buf = nullptr;                                  // items, then results
+    HIP_TRY(hipMalloc((void**)&d_buf, (size_t)n * 32));
+    hipError_t e = hipMemcpy(d_buf, items, (size_t)n * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = svr::launch_chain_selftest(d_buf, d_buf + n, n, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e == hipSuccess) e = hipMemcpy(results, d_buf + n, (size_t)n * 16, hipMemcpyDeviceToHost);
+    hipFree(d_buf);
+    if (e != hipSuccess) return fail((int)e, "svr_selftest_chain failed: %s", hipGetErrorName(e));
     return 0;
 }
 

@@ -116,6 +116,8 @@ int parse_mhd(const char* path, svr_mhd_header* h, std::vector<std::string>* sli
     if (h->ndims < 2 || h->ndims > 3) return failf(-21, "%s: NDims = %d (2 or 3 supported)", path, h->ndims);
     if (h->ndims == 2) h->dim[2] = 1;
     if (h->elem_type < 0) return failf(-21, "%s: no ElementType", path);
+    if ((uint64_t)(h->dim[0] > 0 ? h->dim[0] : 0) * (uint64_t)(h->dim[1] > 0 ? h->dim[1] : 0) * (uint64_t)(h->dim[2] > 0 ? h->dim[2] : 0) >= (1ull << 31))
+        return failf(-21, "%s: %d x %d x %d voxels exceed what one volume texture can address", path, h->dim[0], h->dim[1], h->dim[2]);
     for (int a = 0; a < 3; ++a) {
         if (h->dim[a] <= 0) return failf(-21, "%s: bad DimSize", path);
         h->spacing[a] = std::fabs(h->spacing[a]);

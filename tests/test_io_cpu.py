@@ -72,6 +72,8 @@ def test_mhd_header_variants_and_errors(lib, tmp_path):
         "ascii.mhd": "ObjectType = Image\nNDims = 3\nBinaryData = False\nDimSize = 1 1 1\nElementType = MET_UCHAR\nElementDataFile = x.raw\n",
         "dims.mhd": "ObjectType = Image\nNDims = 4\nDimSize = 1 1 1 1\nElementType = MET_UCHAR\nElementDataFile = x.raw\n",
         "garbage.mhd": "this is not a header\n",
+        "huge.mhd": "ObjectType = Image\nNDims = 3\nDimSize = 4096 4096 4096\nElementType = MET_SHORT\nElementDataFile = x.raw\n",
+        "negdim.mhd": "ObjectType = Image\nNDims = 3\nDimSize = 4 -3 2\nElementType = MET_SHORT\nElementDataFile = x.raw\n",
         "pattern.mhd": "ObjectType = Image\nNDims = 3\nDimSize = 2 2 2\nElementType = MET_UCHAR\nElementDataFile = s%03d.raw 0 1 1\n",
     }
     for name, text in bad.items():
