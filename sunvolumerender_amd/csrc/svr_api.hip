@@ -562,9 +562,13 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
                 return trace_group(next_set(), next_first, (uint32_t)Context::GROUP, 0, false);
             return 0;
         }
+        // at most 2 GB of scratch frames per set (32 frames up to ~2300^2 pixels; fewer for larger images)
+        const uint64_t slot_bytes = (uint64_t)3 * s.imageW * s.imageH * sizeof(float);
+        uint32_t batch_max = 1;
+        while (batch_max < (uint32_t)Context::GROUP && 2ull * batch_max * slot_bytes <= (2ull << 30)) batch_max *= 2u;
         uint32_t batch = 1;
-        while (batch < (uint32_t)Context::GROUP && 2u * batch <= n + 1u) batch *= 2u;
-        if (batch > 1 && ensure_slots(s.imageW, s.imageH, (uint32_t)Context::GROUP)) return g.err_code;
+        while (batch < batch_max && 2u * batch <= n + 1u) batch *= 2u;
+        if (batch > 1 && ensure_slots(s.imageW, s.imageH, batch_max)) return g.err_code;
         return trace_group(next_set(), n, batch, 1, want_img);
     }
 
