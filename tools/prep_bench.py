@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """Time the volume-load preprocessing (svr_volume_preprocess: cast, range, gradient maximum, rescale, histogram)
-on a synthetic 512^3 MET_SHORT volume resident in HBM, against the HBM roofline and the CPU restatement."""
+on a synthetic 512^3 MET_SHORT volume resident in HBM, against the HBM roofline."""
 import ctypes as C
 import sys
-import time
 from pathlib import Path
 
 import numpy as np
@@ -32,10 +31,3 @@ for it in range(6):
 print(f"svr_volume_preprocess {n}^3 {dtype.name}: {best:.3f} ms  {hu.size / best / 1e6:.1f} Gvoxel/s  "
       f"{nbytes.value / best / 1e6:.1f} GB/s algorithmic ({nbytes.value / hu.size:.0f} B/voxel) = {nbytes.value / best / 1e6 / 8000:.3f} of 8 TB/s; "
       f"range {info.range[0]:.0f}..{info.range[1]:.0f}, maxMagnitude {info.maxMagnitude:.0f}, bins {info.hist_bins}")
-if "--cpu" in sys.argv:
-    from oracle import binding
-    sub = hu[: max(1, n // 8)]
-    t0 = time.perf_counter()
-    binding.io_preprocess(sub, (1.0, 1.0, 1.0))
-    dt = time.perf_counter() - t0
-    print(f"oracle (CPU restatement, OpenMP gradient only) on {sub.shape[0]} slices: {sub.size / dt / 1e6:.1f} Mvoxel/s")
