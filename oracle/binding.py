@@ -60,6 +60,7 @@ def build(force: bool = False) -> Path:
     if force or not LIB.exists() or any(LIB.stat().st_mtime < f.stat().st_mtime for f in srcs):
         subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "libsvr_oracle.so"], check=True, capture_output=True)
     build_ref(force)
+    build_fresnel_ref(force)
     return LIB
 
 
@@ -70,6 +71,42 @@ def build_ref(force: bool = False):
                                                          or STB_REF.stat().st_mtime < (ORACLE_DIR / "stb_ref.c").stat().st_mtime):
         subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "_ref/libstb_ref.so"], check=True, capture_output=True)
     return STB_REF if STB_REF.exists() else None
+
+
+FRESNEL_REF = ORACLE_DIR / "_ref" / "libref_fresnel.so"
+
+
+def _cuda_include_dir():
+    """A directory with a genuine cuda_runtime.h (the triton wheel ships NVIDIA's headers), or None."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("triton")
+        if spec and spec.origin:
+            d = Path(spec.origin).parent / "backends" / "nvidia" / "include"
+            if (d / "cuda_runtime.h").exists():
+                return d
+    except Exception:
+        pass
+    return None
+
+
+def build_fresnel_ref(force: bool = False):
+    """oracle/_ref/libref_fresnel.so: the reference's own schlick_fresnel (core/bsdf/fresnel.h) compiled where it lies."""
+    inc = _cuda_include_dir()
+    if (REFERENCE / "core" / "bsdf" / "fresnel.h").exists() and inc is not None and (
+            force or not FRESNEL_REF.exists() or FRESNEL_REF.stat().st_mtime < (ORACLE_DIR / "ref_fresnel.cpp").stat().st_mtime):
+        subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "_ref/libref_fresnel.so", f"CUDA_INC={inc}"], check=True, capture_output=True)
+    return FRESNEL_REF if FRESNEL_REF.exists() else None
+
+
+def fresnel_ref():
+    path = build_fresnel_ref()
+    if path is None:
+        return None
+    lib = C.CDLL(str(path))
+    lib.ref_schlick_fresnel.restype = C.c_float
+    lib.ref_schlick_fresnel.argtypes = [C.c_float, C.c_float, C.c_float]
+    return lib
 
 
 _stb = None

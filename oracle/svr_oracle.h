@@ -7,8 +7,12 @@
  *
  * PARITY UNPINNED: the reference (sunwj/SunVolumeRender) ships no tests, golden
  * images or fixtures for this path, and it cannot be built in this image (it needs
- * the CUDA runtime, cuRAND device headers and GLM, none of which exist here, and
- * writing stand-ins for them is not allowed).  The oracle is therefore a plain-C
+ * cuRAND device headers and GLM, which do not exist here, and writing stand-ins for
+ * them is not allowed).  One function is the exception: schlick_fresnel
+ * (core/bsdf/fresnel.h) needs only <cuda_runtime.h>, a genuine copy of which ships
+ * inside the triton wheel; oracle/ref_fresnel.cpp builds it where it lies and
+ * svo_schlick matches it bit for bit (tests/test_oracle_kat.py).  Everything else
+ * is unpinned.  The oracle is therefore a plain-C
  * restatement of the reference's arithmetic and control flow, function by function,
  * each citing the reference file:line it follows.  Three things the reference
  * delegates to absent third parties are *defined* here and shared, as a written
