@@ -290,3 +290,22 @@ def test_cpp_canvas_example_matches_python_canvas(hip_dev, tmp_path):
         hip_dev.set_option(abi.OPT_ENV_ON_ESCAPE, 0)
         canvas.close()
         tf.close()
+
+
+def test_preprocess_full_size_512(hip_dev):
+    """BASELINE-size volume (512^3, MET_SHORT): the GPU preprocessing against the CPU restatement, plus
+    size-independent properties of the result."""
+    u = scenes.make_scene("c3").vox                                            # cached 512^3 u16 phantom
+    hu = (u.astype(np.int32) * 3000 // 65535 - 1000).astype(np.int16)           # -1000 .. 2000
+    spacing = (0.8, 0.8, 1.25)
+    got = _preprocess(hip_dev, hu, spacing, on_device=True)
+    ref = binding.io_preprocess(hu, spacing)
+    _check(got, ref, "512^3")
+    assert got["u16"].min() == 0 and got["u16"].max() == 65535
+    lo, hi = int(hu.min()), int(hu.max())
+    assert got["range"] == (lo, hi) and got["hist_bins"] == hi - lo
+    # every voxel lands in exactly one bin except zeros (IgnoreZero) and the maximum (outside the extent)
+    assert int(got["hist"].astype(np.int64).sum()) == hu.size - int((hu == 0).sum()) - int((hu == hi).sum())
+    # rescaling is monotone
+    order = np.argsort(hu.ravel()[:: 4099], kind="stable")
+    assert np.all(np.diff(got["u16"].ravel()[:: 4099][order].astype(np.int64)) >= 0)
