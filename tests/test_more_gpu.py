@@ -457,3 +457,53 @@ def test_sample_chain_primitives(hip_dev):
             assert ta == x, (a[i], ta, x)
         n_exact += bool(fl & 1) + bool(fl & 2) + bool(fl & 4)
     assert n_exact > 2 * len(a)          # the closed form covers most chains
+
+
+@pytest.mark.parametrize("case", ["voxel_1", "vol_3x2x2", "image_2x2", "tf_transparent", "tf_opaque", "dense_scale", "shard_more_ranks_than_strips"])
+def test_degenerate_scenes(hip_dev, case):
+    """Corner cases of the acceleration data and the work distribution: one-voxel and few-voxel volumes (a 1x1x1
+    macro grid), a 2x2-pixel image, a transfer function that is transparent everywhere (every ray is skipped) or
+    opaque everywhere (no cell is empty: distance 0 everywhere), a density scale that saturates the table, and
+    more ranks than strips (some ranks own nothing).  Path tracer (per-frame calls and one 16-frame launch) and ray
+    caster against the oracle."""
+    base = scenes.make_scene("tiny_head", trace_depth=2)
+    sc = base
+    shard = None
+    if case == "voxel_1":
+        sc = dataclasses.replace(base, vox=np.full((1, 1, 1), 40000, dtype=np.uint16), max_magnitude=100.0)
+    elif case == "vol_3x2x2":
+        v = (np.arange(12, dtype=np.uint16).reshape(2, 2, 3) * 5000 + 3000).astype(np.uint16)
+        sc = dataclasses.replace(base, vox=v, spacing=(1.0, 2.0, 0.5), max_magnitude=scenes.max_gradient_magnitude(v, (1.0, 2.0, 0.5)))
+    elif case == "image_2x2":
+        sc = dataclasses.replace(base, width=2, height=2)      # (1x1 divides by W - 1 = 0, cuda_camera.h:68: NaN in the reference too)
+    elif case == "tf_transparent":
+        tf = base.tf_rgba.copy(); tf[:, 3] = 0.0
+        sc = dataclasses.replace(base, tf_rgba=tf, max_opacity=0.5)
+    elif case == "tf_opaque":
+        tf = base.tf_rgba.copy(); tf[:, 3] = 1.0
+        sc = dataclasses.replace(base, tf_rgba=tf, max_opacity=1.0)
+    elif case == "dense_scale":
+        sc = dataclasses.replace(base, density_scale=37.5)
+    elif case == "shard_more_ranks_than_strips":
+        shard = (32, 5, 7)                                   # 80 rows = 3 strips of 32 for 7 ranks: rank 5 owns nothing
+    if sc.camera is None and case in ("voxel_1", "vol_3x2x2"):
+        sc = dataclasses.replace(sc, lights=[host.place_area_light(20.0, 30.0, 12.0, 3.0, (1, 1, 1), 300.0)])
+    for frames, batch in ((3, False), (16, True)):
+        ref_hdr, ref_img, ref_c = oracle_frames(sc, frames)
+        hdr, img, c = hip_frames(hip_dev, sc, frames, batch=batch, shard=shard)
+        if shard is None:
+            assert_bit_exact(hdr, ref_hdr, f"{case} {frames} frames batch={batch}")
+            assert np.array_equal(img, ref_img)
+            assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"]
+        else:
+            assert not hdr.any() and c["paths"] == 0         # this rank owns no rows: nothing rendered, nothing touched
+    if shard is None:
+        ref_rc, rc = binding.OracleScene(sc).render_raycasting()
+        canvas = host.Canvas(hip_dev, sc.width, sc.height)
+        try:
+            scenes.apply_to_canvas(sc, canvas)
+            canvas.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING)
+            canvas.paint(sync=True)
+            assert np.array_equal(canvas.read_img(), ref_rc)
+        finally:
+            canvas.close()
