@@ -1,7 +1,8 @@
 import sys
 sys.path.insert(0,'.')
 from sunvolumerender_amd import abi, host, scenes
-sc = scenes.make_scene("c3")
+import os
+sc = scenes.make_scene("c3", trace_depth=int(os.environ.get("DEPTH", "1")))
 dev = host.Device(0)
 c = host.Canvas(dev, sc.width, sc.height)
 scenes.apply_to_canvas(sc, c, 0)
