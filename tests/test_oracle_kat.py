@@ -299,3 +299,26 @@ def test_schlick_fresnel_against_the_reference_itself(oracle):
         for _ in range(2000):
             a, b, c = (float(np.float32(v)) for v in (rs.uniform(0.5, 3), rs.uniform(0.5, 3), rs.uniform(-1, 1)))
             assert np.float32(ref.ref_schlick_fresnel(a, b, c)).view(np.uint32) == np.float32(oracle.svo_schlick(a, b, c)).view(np.uint32)
+
+
+def test_config_c1_cpu_plumbing():
+    """BASELINE config 0 -- the reference's own CPU-runnable case: ray casting (and one path-traced frame) of the 64^3
+    sphere at 256^2 through the oracle alone, no GPU.  Deterministic, image properties as expected, and the images'
+    digests are pinned so an accidental change of the numeric contract shows here first."""
+    import hashlib
+    from oracle import binding
+    from sunvolumerender_amd import scenes
+    sc = scenes.make_scene("c1")
+    assert sc.dim == (64, 64, 64) and (sc.width, sc.height) == (256, 256)
+    o = binding.OracleScene(sc)
+    img, c = o.render_raycasting()
+    img2, c2 = o.render_raycasting(nthreads=1)
+    assert np.array_equal(img, img2) and c == c2                       # thread count does not matter
+    assert c["raycast_steps"] == 3458072 and c["vol_taps"] == 7 * c["raycast_steps"]
+    assert hashlib.sha256(img.tobytes()).hexdigest() == "597dc2725cd7303bf9bc1ce5710ca14acb19f06a0e92fc5e8f9728a609c5c405"
+    cover = (img[..., 3] > 0)
+    assert 0.15 < cover.mean() < 0.25 and cover[128, 128] and not cover[5, 5]     # the sphere in the middle of the frame
+    hdr = o.new_hdr()
+    cc = o.render_pathtracer(hdr, 0)
+    assert cc["paths"] == 65536 and cc["vol_taps"] == 850779
+    assert hashlib.sha256(hdr.tobytes()).hexdigest() == "36cdd1149c5d5485700536b91937fc78523038d1d002eec6d632c0287a3253e4"
