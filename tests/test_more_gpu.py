@@ -507,3 +507,31 @@ def test_degenerate_scenes(hip_dev, case):
             assert np.array_equal(canvas.read_img(), ref_rc)
         finally:
             canvas.close()
+
+
+@pytest.mark.parametrize("name,frames", [("c1", 4), ("c2", 2)])
+def test_baseline_configs_full_frame(hip_dev, name, frames):
+    """BASELINE configs 0 and 1 (64^3 sphere at 256^2; 256^3 head at 512^2, one light) at their full image sizes:
+    path tracer (per-frame calls and one many-frame launch) and ray caster against the oracle, every pixel."""
+    sc = scenes.make_scene(name)
+    ref_hdr, ref_img, ref_c = oracle_frames(sc, frames)
+    hdr, img, c = hip_frames(hip_dev, sc, frames)
+    assert_bit_exact(hdr, ref_hdr, f"{name} {frames} frames")
+    assert np.array_equal(img, ref_img)
+    assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"] and c["paths"] == ref_c["paths"]
+    n = 8 if name == "c2" else 32
+    ref_n, _, _ = oracle_frames(sc, n)
+    got_n, _, _ = hip_frames(hip_dev, sc, n, batch=True, count=False)
+    assert_bit_exact(got_n, ref_n, f"{name} one {n}-frame launch")
+    ref_rc, rc = binding.OracleScene(sc).render_raycasting()
+    canvas = host.Canvas(hip_dev, sc.width, sc.height)
+    try:
+        scenes.apply_to_canvas(sc, canvas)
+        canvas.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING)
+        hip_dev.set_option(abi.OPT_COUNT, 1); hip_dev.reset_counters()
+        canvas.paint(sync=True)
+        assert np.array_equal(canvas.read_img(), ref_rc)
+        assert hip_dev.counters()["raycast_steps"] == rc["raycast_steps"]
+    finally:
+        hip_dev.set_option(abi.OPT_COUNT, 0)
+        canvas.close()
