@@ -1,26 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s (paths x spp per second) of the path-tracing hot path on MI355X.
 
-Workload (BASELINE.json metric: "Msamples/sec at 1024^2 on 512^3 volume"): config c3 = 512^3 CT-like
-volume, 1024^2 image, 3 area lights + environment map, GUI-default transfer function, trace depth 1
-(the reference's default, gui/canvas.cpp:17).  A *step* is one progressive-render pass over the whole
-frame: `--spp-per-step` samples for every pixel (default 32 = one frame group = one launch of the trace
-kernel through svr_render_pathtracer_frames, bit-identical to 32 render_pathtracer calls; the default
-8 steps are config c3's 256 spp; `--spp-per-step 1` is the reference's one-call-per-frame protocol).  With N GPUs the frame is sharded into interleaved 32-row strips
-(global per-pixel seeds, so the assembled image is bit-identical to one GPU) and the HDR accumulation
-buffers are summed onto rank 0 with one RCCL reduce per output, inside the timed region.
+Workload (BASELINE.json metric: "Msamples/sec at 1024^2 on 512^3 volume"): config c3 = 512^3 CT-like volume, 1024^2
+image, 3 area lights + environment map, GUI-default transfer function, trace depth 1 (the reference's default,
+gui/canvas.cpp:17).  A *step* is one complete progressive render of the configuration: `--spp-per-step` samples for
+every pixel (default 256 = c3's spp), issued as ONE svr_render_pathtracer_frames call = 8 trace launches of 32 frames,
+bit-identical to 256 render_pathtracer calls (`--spp-per-step 1` is the reference's one-call-per-frame protocol).
 
-One JSON line on rank 0; see the task contract for the field meanings.  `roofline` prices the
-path-tracing kernel by algorithmic bytes (16 B per volume tap + 24 B HDR read-modify-write per pixel
-per launch) over its HIP-event duration; `cpu_baseline` times the CPU oracle (a plain-C
-port of the reference's arithmetic, OpenMP over rows) on a bounded sample of the same workload.
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (torch.distributed.run,
+before this process touches the GPU); under an external launcher (RANK / WORLD_SIZE set) it is one of the ranks.  With
+N > 1 the frame is sharded into interleaved 16-row strips (global per-pixel seeds: the assembled image is bit-identical
+to one GPU's); inside the timed region the ranks' strips are gathered onto rank 0 over RCCL (one collective per output,
+sunvolumerender_amd.dist.FrameAssembler) and rank 0 tone-maps the assembled frame (svr_hdr_to_ldr_frame).
+
+One JSON line on rank 0 (the task contract's fields) plus
+  roofline      what bounds the dominant kernel (k_trace_tile).  The counters say vector-instruction issue, not HBM
+                (profiles/): `bound` = "valu_issue", `achieved` = wave64 VALU instructions per second (instructions
+                per launch from the committed rocprofv3 --pmc SQ_INSTS_VALU pass of the same workload / the HIP-event
+                launch duration measured live), `peak` = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64
+                instruction (MI355X_MICROARCH.md).  The SURVEY 8(d) byte figure (16 B per volume tap of the REFERENCE
+                algorithm + 24 B per pixel per launch) is kept as `algorithmic_*`; on the headline scene 95 % of those
+                taps are proven transparent and never fetched, so `algorithmic_demand_frac` can exceed 1 and is not a
+                fraction of anything -- `hbm_traffic_bytes` is what HBM really moved.
+  workloads     the same measurement on the scenes where nothing can be skipped and algorithmic bytes = executed
+                bytes: c3 with noisy, non-zero air (`c3n`), and c3 with empty-space skipping switched off.
+  cpu_baseline  the CPU oracle (a plain-C port of the reference's arithmetic, OpenMP) on a bounded sample.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -29,7 +43,9 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0     # wave64 VALU instructions per ns: 2 cycles each on a SIMD-32 -> 1228.8 G/s
+METRIC = "Msamples/sec (paths x spp) at 1024^2 on 512^3 volume"
 
 
 def parse_args():
@@ -39,14 +55,32 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="c3")
     ap.add_argument("--trace-depth", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=32)
+    ap.add_argument("--spp-per-step", type=int, default=256)
     ap.add_argument("--kernel", type=int, default=0, help="0 auto(=2), 1 block-per-tile baseline, 2 persistent tile kernel, 3 lane state machine")
     ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 linear, 2 brick")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--strip-rows", type=int, default=16, help="rows per interleaved strip under row sharding (16: max/mean rank time 1.02 at 8 ranks on c3, 32: 1.08)")
+    ap.add_argument("--assemble", default="gather", choices=["gather", "reduce"], help="collective that assembles the frame on rank 0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget (0 = skip)")
-    ap.add_argument("--no-count", action="store_true", help="skip the tap-counting pass (roofline.achieved = null)")
+    ap.add_argument("--no-count", action="store_true", help="skip the tap-counting pass (algorithmic_* = null)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (noisy air, skipping off)")
+    ap.add_argument("--extra-steps", type=int, default=2)
+    ap.add_argument("--empty-skip", type=int, default=1)
+    ap.add_argument("--fast-math", type=int, default=0)
     return ap.parse_args()
+
+
+def launch_ranks(n: int) -> int:
+    """Start the n ranks as children of this (GPU-free) process and pass rank 0's line through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(scene, trace_depth, budget_s):
@@ -105,19 +139,121 @@ def _cpu_model() -> str:
     return "unknown"
 
 
+def kernel_source_hash() -> str:
+    """Hash of the kernel sources: a committed PMC record made from other sources is flagged as stale."""
+    h = hashlib.sha1()
+    for f in sorted((ROOT / "sunvolumerender_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".hpp"):
+            h.update(f.read_bytes())
+    return h.hexdigest()[:12]
+
+
+def pmc_record(tag: str):
+    """profiles/r02_pmc_<tag>.json: per-launch averages of the rocprofv3 --pmc passes of this workload (tools/pmc_json.py)."""
+    f = ROOT / "profiles" / f"r02_pmc_{tag}.json"
+    if not f.exists():
+        return None
+    try:
+        rec = json.loads(f.read_text())
+        rec["_file"] = str(f.relative_to(ROOT))
+        return rec
+    except Exception:
+        return None
+
+
+class Workload:
+    """One scene on one canvas: counting pass, warm-up, timed steps."""
+
+    def __init__(self, dev, torch, name, trace_depth, layout):
+        from sunvolumerender_amd import host, scenes
+
+        self.dev, self.torch, self.name = dev, torch, name
+        self.scene = scenes.make_scene(name, trace_depth=trace_depth)
+        W, H = self.scene.width, self.scene.height
+        self.hdr = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+        self.img = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+        self.canvas = host.Canvas(dev, W, H, img_ptr=self.img.data_ptr(), hdr_ptr=self.hdr.data_ptr())
+        scenes.apply_to_canvas(self.scene, self.canvas, layout)
+
+    def step(self, S):
+        if S == 1:
+            self.canvas.paint()
+        else:
+            self.canvas.paint_frames(S)
+
+    def count(self, steps, S):
+        from sunvolumerender_amd import abi
+
+        self.dev.set_option(abi.OPT_COUNT, 1)
+        self.dev.reset_counters()
+        self.canvas.ReStartRender()
+        for _ in range(steps):
+            self.step(S)
+        self.torch.cuda.synchronize()
+        c = self.dev.counters()
+        self.dev.set_option(abi.OPT_COUNT, 0)
+        return c
+
+    def close(self):
+        self.canvas.close()
+
+
+def roofline_block(counters, S, steps, k_ms, k_n, pmc):
+    """Flat roofline record for one timed workload of this rank (see the module docstring)."""
+    roof = {"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave64 VALU instr/s",
+            "frac": None, "traffic": None, "kernel": "k_trace_tile", "kernel_avg_ms": None, "kernel_launches": k_n}
+    if k_n <= 0:
+        return roof
+    avg_ms = k_ms / k_n
+    roof["kernel_avg_ms"] = round(avg_ms, 4)
+    if counters is not None:
+        owned_px = counters["paths"] / (S * steps)
+        # SURVEY.md 8(d): 16 B per volume tap of the algorithm + 24 B HDR read-modify-write per pixel per launch
+        alg = (16.0 * counters["vol_taps"] + 24.0 * owned_px * k_n) / k_n
+        exe = (16.0 * counters["vol_taps_executed"] + 24.0 * owned_px * k_n) / k_n
+        roof.update({
+            "algorithmic_bytes_per_launch": int(alg),
+            "algorithmic_demand_gbs": round(alg / (avg_ms * 1e-3) / 1e9, 1),
+            "algorithmic_demand_frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "executed_bytes_per_launch": int(exe),
+            "executed_demand_frac": round(exe / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "vol_taps_per_path": round(counters["vol_taps"] / max(1, counters["paths"]), 3),
+            "executed_taps_per_path": round(counters["vol_taps_executed"] / max(1, counters["paths"]), 3),
+        })
+    if pmc is not None:
+        stale = pmc.get("kernel_source_hash") not in (None, kernel_source_hash())
+        roof.update({"pmc_source": pmc["_file"], "pmc_stale": bool(stale)})
+        if pmc.get("valu_insts_per_launch"):
+            ach = pmc["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9
+            roof.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GINST_S, 4),
+                         "valu_insts_per_launch": int(pmc["valu_insts_per_launch"]),
+                         "valu_peak_ginst_s": round(VALU_PEAK_GINST_S, 1),
+                         "lane_utilisation": pmc.get("valu_lane_utilisation")})
+        if pmc.get("traffic_bytes_per_launch"):
+            t = pmc["traffic_bytes_per_launch"]
+            roof.update({"traffic": int(t), "hbm_traffic_bytes": int(t), "hbm_peak_gbs": HBM_PEAK_GBS,
+                         "hbm_frac_traffic": round(t / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
+    return roof
+
+
 def main():
     args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # no launcher around us: become the launcher.  Nothing in this process has touched the GPU yet.
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; start it as `python bench.py --gpus N` "
+                         f"or under torch.distributed.run with --nproc-per-node equal to --gpus")
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
-    import torch.distributed as dist
+    import torch.distributed as tdist
 
-    from sunvolumerender_amd import abi, host, scenes
+    from sunvolumerender_amd import abi, dist, host
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
@@ -128,56 +264,56 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            tdist.init_process_group(backend, rank=rank, world_size=world)
 
     t_setup = time.perf_counter()
-    scene = scenes.make_scene(args.scene, trace_depth=args.trace_depth)
-    W, H = scene.width, scene.height
     dev = host.Device(local_rank, fatal_errors=False)
     stream = torch.cuda.current_stream()
     dev.check(dev.lib.svr_set_stream(C.c_void_p(stream.cuda_stream)))
-    hdr = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
-    img = torch.zeros(H * W, dtype=torch.int32, device="cuda")
-    canvas = host.Canvas(dev, W, H, img_ptr=img.data_ptr(), hdr_ptr=hdr.data_ptr())
-    scenes.apply_to_canvas(scene, canvas, args.layout)
+    wl = Workload(dev, torch, args.scene, args.trace_depth, args.layout)
+    scene, canvas = wl.scene, wl.canvas
+    W, H = scene.width, scene.height
     dev.set_option(abi.OPT_KERNEL, args.kernel)
+    dev.set_option(abi.OPT_EMPTY_SKIP, args.empty_skip)
+    if args.fast_math:
+        dev.set_option(abi.OPT_FAST_MATH, 1)
     if args.blocks_per_cu:
         dev.set_option(abi.OPT_BLOCKS_PER_CU, args.blocks_per_cu)
+    asm = None
     if world > 1:
-        dev.check(dev.lib.svr_set_row_shard(args.strip_rows, rank, world))
+        dist.shard(dev, args.strip_rows, rank, world)
+        asm = dist.FrameAssembler(H, W, args.strip_rows, rank, world, dst=0, mode=args.assemble)
+        frame_img = torch.zeros(H * W, dtype=torch.int32, device="cuda") if rank == 0 else None
     S = max(1, args.spp_per_step)
     t_setup = time.perf_counter() - t_setup
-
-    def step():
-        if S == 1:
-            canvas.paint()
-        else:
-            canvas.paint_frames(S)
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            tdist.barrier()
         torch.cuda.synchronize()
+
+    def assemble_and_tonemap(hdr):
+        """The output of a sharded render: strips -> rank 0 (one collective), full-frame tone map on rank 0."""
+        src = hdr if backend == "nccl" else hdr.cpu()
+        frame = asm.assemble(src)
+        if rank == 0:
+            if frame.device.type != "cuda":
+                frame = frame.cuda()
+            dev.check(dev.lib.svr_hdr_to_ldr_frame(C.c_void_p(frame_img.data_ptr()), C.c_void_p(frame.data_ptr()), W, H))
+        return frame
 
     # ---- tap-counting pass (untimed): exact algorithmic bytes of the frames about to be timed ----
-    counters = None
-    if not args.no_count:
-        dev.set_option(abi.OPT_COUNT, 1)
-        dev.reset_counters()
-        canvas.ReStartRender()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        counters = dev.counters()
-        dev.set_option(abi.OPT_COUNT, 0)
+    counters = None if args.no_count else wl.count(args.steps, S)
 
-    # ---- warm-up ----
+    # ---- warm-up (includes one assembly, so that its staging buffers and the RCCL channels exist) ----
     canvas.ReStartRender()
     for _ in range(args.warmup):
-        step()
+        wl.step(S)
+    if world > 1:
+        assemble_and_tonemap(wl.hdr)
     # ---- timed region: exactly K steps (frames 0 .. K*S-1 of a fresh progressive render) ----
     canvas.ReStartRender()
     dev.set_option(abi.OPT_TIMING, 1)
@@ -185,15 +321,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        wl.step(S)
     if world > 1:
-        # one collective per output: strips are disjoint and every rank's buffer is zero outside its own
-        if backend == "nccl":
-            dist.reduce(hdr, dst=0, op=dist.ReduceOp.SUM)
-        else:
-            h = hdr.cpu()
-            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
-            hdr.copy_(h)
+        assemble_and_tonemap(wl.hdr)
     barrier()
     elapsed = time.perf_counter() - t0
     dev.set_option(abi.OPT_TIMING, 0)
@@ -201,69 +331,26 @@ def main():
 
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        tdist.all_reduce(el, op=tdist.ReduceOp.MAX)
     elapsed = float(el.item())
 
     # local counters -> whole-job (every rank counts its own strips)
     cnt = None
+    keys = ["paths", "vol_taps", "vol_taps_executed", "woodcock_iters", "scatter_events", "shadow_walks"]
     if counters is not None:
-        keys = ["paths", "vol_taps", "vol_taps_executed", "woodcock_iters", "scatter_events", "shadow_walks"]
         tc = torch.tensor([counters[k] for k in keys], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        local = {k: counters[k] for k in keys}
         if world > 1:
-            dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+            tdist.all_reduce(tc, op=tdist.ReduceOp.SUM)
         cnt = {k: int(v) for k, v in zip(keys, tc.tolist())}
-        cnt["local"] = local
 
     if rank == 0:
         samples = float(W) * H * S * args.steps
         value = samples / elapsed / 1e6
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
-        if cnt is not None and k_n > 0:
-            loc = cnt["local"]
-            n_launch = k_n
-            owned_px = loc["paths"] / (S * args.steps)
-            # 16 B per volume tap of the algorithm + 24 B HDR read-modify-write per pixel per launch
-            bytes_per_launch = (16.0 * loc["vol_taps"] + 24.0 * owned_px * args.steps) / n_launch
-            avg_ms = k_ms / k_n
-            ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            agg = bytes_per_launch * n_launch / elapsed / 1e9
-            roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5),
-                         "achieved_aggregate": round(agg, 2), "frac_aggregate": round(agg / HBM_PEAK_GBS, 5),
-                         "note": "achieved = algorithmic bytes of the reference algorithm per launch (16 B per volume "
-                                 "tap it would fetch + 24 B HDR per pixel-frame) / mean HIP-event duration of one launch. "
-                                 "The kernel does not fetch the taps of provably transparent macro-cells (bit-exact "
-                                 "empty-space skipping), so frac can exceed 1: `traffic` is what HBM really moved. The "
-                                 "kernel is VALU-issue bound (profiles/r01_bench_default_prof_summary.txt), not HBM bound",
-                         "executed_taps_per_path": round(loc["vol_taps_executed"] / max(1, loc["paths"]), 3),
-                         "kernel": {0: "k_trace_tile", 1: "k_pathtrace_pixel", 2: "k_trace_tile", 3: "k_pathtrace_uloop"}[args.kernel],
-                         "kernel_avg_ms": round(avg_ms, 4), "kernel_launches": k_n,
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "vol_taps_per_path": round(loc["vol_taps"] / max(1, loc["paths"]), 3)})
-        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (committed under profiles/); it cannot be
-        # measured from inside this process
-        tfile = ROOT / "profiles" / f"r01_traffic_k_trace_tile_{args.scene}_s{S}.json"
-        if args.kernel in (0, 2) and world == 1 and tfile.exists():
-            try:
-                trec = json.loads(tfile.read_text())
-                roof["traffic"] = trec["traffic_bytes_per_launch"]
-                if trec.get("valu_insts_per_launch") and roof.get("kernel_avg_ms"):
-                    # the bound this kernel really runs against: vector-instruction issue.  A wave64 VALU instruction
-                    # takes 2 cycles of a SIMD-32 (MI355X_MICROARCH.md), 256 CUs x 4 SIMDs at 2.4 GHz
-                    peak = 256 * 4 * 2.4e9 / 2.0
-                    ach = trec["valu_insts_per_launch"] / (roof["kernel_avg_ms"] * 1e-3)
-                    roof["valu_issue"] = {"achieved": round(ach / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "G wave64 instr/s",
-                                          "frac": round(ach / peak, 4), "lane_utilisation": trec.get("valu_lane_utilisation"),
-                                          "insts_per_launch": trec["valu_insts_per_launch"],
-                                          "note": "instruction count from the committed rocprofv3 --pmc SQ_INSTS_VALU pass"}
-                roof["traffic_source"] = str(tfile.relative_to(ROOT))
-                if roof.get("kernel_avg_ms"):
-                    # the same fraction on the bytes HBM really moved ("quote the fraction both ways")
-                    roof["frac_traffic"] = round(roof["traffic"] / (roof["kernel_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-            except Exception:
-                pass
+        variant = f"d{args.trace_depth}" + ("" if args.empty_skip else "_noskip") + ("_fast" if args.fast_math else "")
+        pmc = pmc_record(f"{args.scene}_{variant}") if (args.kernel in (0, 2) and world == 1) else None
+        roof = roofline_block(counters, S, args.steps, k_ms, k_n, pmc)
         out = {
-            "metric": "Msamples/sec (paths x spp) at 1024^2 on 512^3 volume",
+            "metric": METRIC,
             "value": round(value, 3),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -281,22 +368,61 @@ def main():
                        "spp_per_step": S, "trace_depth": args.trace_depth,
                        "kernel": {0: "tile", 1: "pixel", 2: "tile", 3: "uloop"}[args.kernel],
                        "layout": {0: "auto(brick)", 1: "linear", 2: "brick"}[args.layout],
-                       "parallelism": f"row-strip tiles x{world}" if world > 1 else "single GPU",
+                       "math": "fast (v_log/v_exp/v_rcp, opt-in)" if args.fast_math else "bit-exact contract",
+                       "parallelism": f"row-strip tiles x{world}, {args.strip_rows}-row strips, {args.assemble} onto rank 0 + "
+                                      f"full-frame tone map inside the timed region" if world > 1 else "single GPU",
                        "device": dev.info(), "setup_s": round(t_setup, 1)},
             "roofline": roof,
         }
+        if asm is not None:
+            out["config"]["assemble_bytes_per_peer"] = asm.bytes_sent_per_rank()
         if cnt is not None:
-            out["counters"] = {k: v for k, v in cnt.items() if k != "local"}
-        if args.cpu_seconds > 0:
+            out["counters"] = cnt
+
+    # ---- secondary workloads (one GPU only): nothing skippable, so algorithmic bytes = executed bytes ----
+    if world == 1 and not args.no_extra and args.scene == "c3" and args.kernel in (0, 2):
+        extra = {}
+        for tag, sc_name, skip in (("c3_noisy_air", "c3n", 1), ("c3_skip_off", "c3", 0)):
+            w2 = wl if sc_name == args.scene else Workload(dev, torch, sc_name, args.trace_depth, args.layout)
+            dev.set_option(abi.OPT_EMPTY_SKIP, skip)
+            n = max(1, args.extra_steps)
+            c2 = None if args.no_count else w2.count(n, S)
+            w2.canvas.ReStartRender()
+            w2.step(S)
+            w2.canvas.ReStartRender()
+            dev.set_option(abi.OPT_TIMING, 1)
+            dev.check(dev.lib.svr_reset_kernel_time())
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                w2.step(S)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            dev.set_option(abi.OPT_TIMING, 0)
+            ms2, n2 = dev.kernel_time()
+            r2 = roofline_block(c2, S, n, ms2, n2, pmc_record(f"{sc_name}_d{args.trace_depth}" + ("" if skip else "_noskip")))
+            extra[tag] = {"value": round(float(W) * H * S * n / dt / 1e6, 3), "unit": "Msamples/s", "steps": n,
+                          "ms_per_step": round(dt / n * 1e3, 3),
+                          "what": ("c3 with noisy non-zero air (64..191 raw LSB, like CT data rescaled to the full u16 range): no "
+                                   "macro-cell is exactly transparent" if sc_name == "c3n" else
+                                   "the headline scene with SVR_OPT_EMPTY_SKIP = 0: every tap of the reference algorithm is fetched"),
+                          "roofline": r2}
+            dev.set_option(abi.OPT_EMPTY_SKIP, args.empty_skip)
+            if w2 is not wl:
+                w2.close()
+        out["workloads"] = extra
+
+    if rank == 0:
+        if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, args.trace_depth, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
 
-    canvas.close()
+    wl.close()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        tdist.barrier()
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -25,7 +25,10 @@
 // ---------------------------------------------------------------------------------------------------
 class VolumeReader {
 public:
+    VolumeReader() = default;
     ~VolumeReader() { ClearDevice(); }
+    VolumeReader(const VolumeReader&) = delete;                // owns a device texture
+    VolumeReader& operator=(const VolumeReader&) = delete;
 
     // VolumeReader.cpp:13-77: the file is parsed on the host; cast, range, rescale, histogram and gradient-magnitude
     // maximum run on the GPU, and the texture is built at the same time (the reference does that in
@@ -87,7 +90,10 @@ class TransferFunction {
 public:
     static const int TABLE_SIZE = SVR_TF_TABLE_SIZE;
 
+    TransferFunction() = default;
     ~TransferFunction() { if (compositeTex) svr_destroy_texture(compositeTex); }
+    TransferFunction(const TransferFunction&) = delete;        // owns a device texture
+    TransferFunction& operator=(const TransferFunction&) = delete;
 
     // vtkPiecewiseFunction::AddPoint / vtkColorTransferFunction::AddRGBPoint: sorted by x, same x replaces
     void AddPoint(double x, double y, double midpoint = 0.5, double sharpness = 0.0)
@@ -155,6 +161,8 @@ class Lights {
 public:
     Lights() { environmentLight.Set(glm::vec3(0.03f)); }                       // lights.cpp:11-14
     ~Lights() { if (envTex) svr_destroy_texture(envTex); }
+    Lights(const Lights&) = delete;                            // owns a device texture
+    Lights& operator=(const Lights&) = delete;
 
     void SetEnvironmentLight(std::string filename)                              // lights.cpp:31-75
     {

@@ -208,8 +208,11 @@ int svr_get_option(int key);
  * +nframes-1) in ONE launch; bit-identical to nframes calls, tone-maps once at the end. */
 int svr_render_pathtracer_frames(void* img, const svr_render_params* renderParams, uint32_t nframes);
 
-/* hdr_to_ldr alone (pathtracer.cu:282-290). */
+/* hdr_to_ldr alone (pathtracer.cu:282-290), over the pixels this process owns (row shard / window). */
 int svr_hdr_to_ldr(void* img, const svr_render_params* renderParams);
+/* hdr_to_ldr over a WHOLE w x h frame, whatever shard or window is set: the tone map of the frame rank 0 has
+ * assembled from the ranks' strips (hdr: device pointer, w*h packed float3; exposure of the last setup_camera). */
+int svr_hdr_to_ldr_frame(void* img, const void* hdr, uint32_t w, uint32_t h);
 
 typedef struct svr_counters {
     uint64_t paths;
@@ -227,6 +230,11 @@ typedef struct svr_counters {
 } svr_counters;
 /* test hook: the ray caster's sample-chain replay on n items (t, h, bound, steps) -> (count <, count <=, t after steps, flags) */
 int svr_selftest_chain(const float* items, float* results, uint32_t n);
+/* test hook: device-side known-answer tests of the numeric contract.  out[i] = fn(in[i*in_stride ...]) evaluated by the
+ * device functions the kernels use: 0 schlick_fresnel(ni, no, cos)  1 logf  2 expf  3 sinf  4 cosf  5 acosf
+ * 6 atan2f(y, x)  7 powf(x, y)  8 k-th curand_uniform of curand_init(seed bits, 0, 0): in = (seed bits, k)
+ * 9 wangHash(bits) as bits  10 log(1 - u) of the Woodcock walk (logf_unit) */
+int svr_selftest_math(int fn, const float* in, uint32_t in_stride, float* out, uint32_t n);
 int svr_get_counters(svr_counters* out);              /* synchronises the launch stream */
 int svr_reset_counters(void);
 

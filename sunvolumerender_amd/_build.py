@@ -17,7 +17,7 @@ CSRC = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
 LIB_PATH = Path(os.environ["SVR_HIP_LIB"]) if os.environ.get("SVR_HIP_LIB") else LIB_DIR / "libsvr_hip.so"
 
-HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_wavefront.hip", "svr_accel.hip", "svr_raycast.hip", "svr_host_io.hip", "svr_volume_prep.hip"]
+HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_wavefront.hip", "svr_accel.hip", "svr_raycast.hip", "svr_host_io.hip", "svr_volume_prep.hip", "svr_selftest.hip"]
 HIP_HEADERS = ["svr_math.hpp", "svr_scene.hpp", "svr_device.hpp", "svr_kernels.hpp", "svr_kernel_common.hpp", "svr_walk.hpp"]
 
 HIPCC_FLAGS = [
@@ -32,6 +32,8 @@ HIPCC_FLAGS = [
     "-Wno-unused-value",
     "-I" + str(REPO_ROOT / "include"),
 ]
+# extra compile flags for experiment builds (e.g. -DSVR_TEST_HOOKS: the timing-ablation options of tools/exp.py)
+HIPCC_FLAGS += os.environ.get("SVR_EXTRA_HIPCC_FLAGS", "").split()
 LINK_LIBS = ["-lz"]          # MetaImage CompressedData (svr_host_io.hip)
 
 

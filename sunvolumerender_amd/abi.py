@@ -135,6 +135,7 @@ OPT_ENV_ON_ESCAPE, OPT_KERNEL, OPT_COUNT, OPT_TIMING, OPT_SKIP_TONEMAP, OPT_BLOC
 OPT_PIPELINE, OPT_REFILL_MIN_IDLE, OPT_EMPTY_SKIP, OPT_RAY_SKIP, OPT_FRAMES_PER_WAVE_LOG2 = 7, 8, 9, 10, 11
 OPT_RAYCAST_LANES_LOG2 = 12
 OPT_FRAME_AHEAD = 13
+OPT_FAST_MATH = 14
 KERNEL_AUTO, KERNEL_PIXEL, KERNEL_TILE, KERNEL_ULOOP, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4
 
 ELEM_I8, ELEM_U8, ELEM_I16, ELEM_U16, ELEM_I32, ELEM_U32, ELEM_F32, ELEM_F64 = range(8)
@@ -194,7 +195,9 @@ PROTOTYPES = {
     "svr_get_option": (C.c_int, [C.c_int]),
     "svr_render_pathtracer_frames": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_uint32]),
     "svr_hdr_to_ldr": (C.c_int, [C.c_void_p, _P(RenderParams)]),
+    "svr_hdr_to_ldr_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "svr_selftest_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "svr_selftest_math": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
     "svr_get_counters": (C.c_int, [_P(Counters)]),
     "svr_reset_counters": (C.c_int, []),
     "svr_get_kernel_time": (C.c_int, [_P(C.c_double), _P(C.c_uint64)]),

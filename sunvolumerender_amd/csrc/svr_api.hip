@@ -153,6 +153,21 @@ int fail(int code, const char* fmt, ...)
     return g.err_code;
 }
 
+// record an error without the fatal-mode exit: misuse that cannot have corrupted anything (e.g. destroying a
+// handle twice from a copied host object)
+int soft_fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g.err_code = code ? code : -1;
+    g.err_msg = buf;
+    if (g.fatal) fprintf(stderr, "libsvr_hip warning %d: %s\n", g.err_code, buf);
+    return g.err_code;
+}
+
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \
@@ -342,6 +357,25 @@ int fill_work(svr::DevWork& w, uint32_t W, uint32_t H)
     return 0;
 }
 
+// the whole frame, whatever shard or window is set
+void fill_work_full(svr::DevWork& w, uint32_t W, uint32_t H)
+{
+    memset(&w, 0, sizeof w);
+    w.counters = g.d_counters;
+    w.ticket = g.d_ticket;
+    w.strip_rows = 1; w.rank = 0; w.world = 1;
+    w.x0 = 0; w.x1 = W; w.y0 = 0; w.y1 = H;
+    w.n_rows = H;
+    w.n_items = W * H;
+}
+
+bool partial_frame(uint32_t W, uint32_t H)
+{
+    svr::DevWork w;
+    fill_work(w, W, H);
+    return w.n_items != W * H;
+}
+
 void collect_timing()
 {
     while (g.ev_count > 0) {
@@ -453,6 +487,11 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     if (add_lights_env(s)) return g.err_code;
     if ((size_t)3 * s.imageW * s.imageH >= ((size_t)1 << 32)) return fail(-3, "image too large");
     if (ensure_slots(s.imageW, s.imageH, nframes < (uint32_t)Context::GROUP ? nframes : (uint32_t)Context::GROUP)) return g.err_code;
+    // clear_hdr_buffer zeroes the WHOLE accumulator at frame 0 (pathtracer.cu:86-94,297-300); under a row shard or a
+    // window the kernels only touch their own pixels, so the rest is cleared here (the strips of the ranks are then
+    // summed into one frame: stale values outside the owned rows would corrupt it)
+    if (rp->frameNo == 0 && partial_frame(s.imageW, s.imageH))
+        HIP_TRY(hipMemsetAsync(rp->hdrBuffer, 0, sizeof(float) * 3 * (size_t)s.imageW * s.imageH, g.stream));
     svr::LaunchCfg cfg;
     cfg.kernel = g.opt_kernel == svr::KERNEL_AUTO ? svr::KERNEL_TILE : g.opt_kernel;
     if ((cfg.kernel == svr::KERNEL_TILE || cfg.kernel == svr::KERNEL_WAVEFRONT) && ensure_mask(s, g.vol, g.tf)) return g.err_code;
@@ -727,6 +766,9 @@ static uint64_t create_float4_texture(int kind, const float* rgba, int w, int h,
     t->magic = TEX_MAGIC; t->kind = kind; t->nx = w; t->ny = h; t->nz = 1; t->layout = 0;
     t->bytes = (size_t)w * h * 4 * sizeof(float);
     hipError_t e = hipMalloc(&t->data, t->bytes);
+    // a device-side table may still be being written by work queued on the caller's stream (torch pool streams do not
+    // synchronise with the null stream): order the copy after it
+    if (e == hipSuccess && src_is_device) e = hipStreamSynchronize(g.stream);
     if (e == hipSuccess) e = hipMemcpy(t->data, rgba, t->bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
     if (e != hipSuccess) { if (t->data) hipFree(t->data); delete t; fail((int)e, "texture upload failed: %s", hipGetErrorName(e)); return 0; }
     uint64_t hd = (uint64_t)(uintptr_t)t;
@@ -786,7 +828,7 @@ int svr_destroy_texture(uint64_t handle)
 {
     if (ensure_init()) return g.err_code;
     auto it = g.textures.find(handle);
-    if (it == g.textures.end()) return fail(-2, "svr_destroy_texture: bad handle");
+    if (it == g.textures.end()) return soft_fail(-2, "svr_destroy_texture: 0x%llx is not a live texture handle (destroyed twice?)", (unsigned long long)handle);
     HIP_TRY(hipDeviceSynchronize());
     Texture* t = it->second;
     if (t->data) hipFree(t->data);
@@ -898,6 +940,23 @@ int svr_hdr_to_ldr(void* img, const svr_render_params* rp)
     return 0;
 }
 
+int svr_hdr_to_ldr_frame(void* img, const void* hdr, uint32_t w_, uint32_t h_)
+{
+    if (ensure_init()) return g.err_code;
+    if (!hdr || !img || w_ == 0 || h_ == 0) return fail(-4, "svr_hdr_to_ldr_frame: bad argument");
+    if (!g.have_cam) return fail(-4, "svr_hdr_to_ldr_frame before setup_camera (the exposure comes from the camera)");
+    svr::DevScene s;
+    memset(&s, 0, sizeof s);
+    s.imageW = w_; s.imageH = h_;
+    s.exposure = g.cam.exposure;
+    svr::DevWork w;
+    fill_work_full(w, w_, h_);
+    w.hdr = (float*)const_cast<void*>(hdr);
+    w.img = (uint8_t*)img;
+    HIP_TRY(svr::launch_tonemap(s, w, g.stream));
+    return 0;
+}
+
 void render_raycasting(void* img, svr_volume* volume, svr_transfer_function* transferFunction, svr_camera* camera, float stepSize)
 {
     if (ensure_init()) return;
@@ -945,8 +1004,11 @@ int svr_set_option(int key, int value)
     case SVR_OPT_PIPELINE: g.opt_pipeline = value ? 1 : 0; return 0;
     case SVR_OPT_EMPTY_SKIP: g.opt_empty_skip = value ? 1 : 0; return 0;
     case SVR_OPT_RAY_SKIP: g.opt_ray_skip = value ? 1 : 0; return 0;
-    case 100: g.opt_debug_stop = value; return 0;      // undocumented timing ablation (wrong images)
-    case 101: g.opt_unit = value; return 0;            // undocumented: tasks per ticket of the tile kernel
+#ifdef SVR_TEST_HOOKS
+    // experiment builds only (tools/exp.py; `SVR_EXTRA_HIPCC_FLAGS=-DSVR_TEST_HOOKS python -m sunvolumerender_amd._build --force`)
+    case 100: g.opt_debug_stop = value; return 0;      // timing ablation: stop every path after a phase (wrong images)
+    case 101: g.opt_unit = value; return 0;            // tasks per ticket of the tile kernel
+#endif
     case SVR_OPT_FRAME_AHEAD: g.opt_frame_ahead = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_RAYCAST_LANES_LOG2:
         if (value < 0 || value > 5) return fail(-6, "SVR_OPT_RAYCAST_LANES_LOG2: bad value %d (0..5)", value);
@@ -994,6 +1056,24 @@ int svr_selftest_chain(const float* items, float* results, uint32_t n)
     if (e == hipSuccess) e = hipMemcpy(results, d_buf + n, (size_t)n * 16, hipMemcpyDeviceToHost);
     hipFree(d_buf);
     if (e != hipSuccess) return fail((int)e, "svr_selftest_chain failed: %s", hipGetErrorName(e));
+    return 0;
+}
+
+// test hook: device-side known-answer tests of the numeric contract (csrc/svr_selftest.hip)
+int svr_selftest_math(int fn, const float* in, uint32_t in_stride, float* out, uint32_t n)
+{
+    if (ensure_init()) return g.err_code;
+    if (!in || !out || n == 0 || in_stride == 0 || in_stride > 4) return fail(-4, "svr_selftest_math: bad arguments");
+    float* d_in = nullptr; float* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, (size_t)n * in_stride * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_out, (size_t)n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, (size_t)n * in_stride * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = svr::launch_math_selftest(fn, d_in, in_stride, d_out, n, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    hipFree(d_in);
+    if (d_out) hipFree(d_out);
+    if (e != hipSuccess) return fail((int)e, "svr_selftest_math(%d) failed: %s", fn, hipGetErrorName(e));
     return 0;
 }
 

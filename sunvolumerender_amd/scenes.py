@@ -57,10 +57,14 @@ def _smooth(edge0, edge1, x):
     return (t * t * (f32(3.0) - f32(2.0) * t)).astype(np.float32)
 
 
-def make_ct_head_volume(n: int, seed: int = 1) -> np.ndarray:
+def make_ct_head_volume(n: int, seed: int = 1, noisy_air: bool = False) -> np.ndarray:
     """'CT-head-like' phantom: nested ellipsoids (skin 0.25, soft tissue 0.35, bone shell 0.8, brain 0.4
     with two dark ventricles) with ~1.5-voxel soft edges and low-amplitude hash noise inside the head;
-    air is exactly 0 so the GUI-default transfer function leaves it transparent."""
+    air is exactly 0 so the GUI-default transfer function leaves it transparent.
+    noisy_air: every voxel is at least 64 + (hash & 127) raw units -- what real CT data looks like after the
+    reference rescales it to the full u16 range (VolumeReader.cpp:124-136): air is noisy and NON-zero, the
+    GUI-default transfer function (alpha > 0 above raw ~32) is nowhere exactly transparent, and no macro-cell can
+    be skipped on the grounds that its opacity is exactly 0."""
     out = np.empty((n, n, n), dtype=np.uint16)
     step = max(1, min(n, (1 << 21) // (n * n)))
     e = f32(1.5 / n)  # edge softness in unit-cube units
@@ -98,7 +102,12 @@ def make_ct_head_volume(n: int, seed: int = 1) -> np.ndarray:
         noise = (wang_hash_np(np.broadcast_to(idx, (nz_, ny_, nx_))).astype(np.float32) / f32(4294967296.0) - f32(0.5))
         d = d + f32(0.03) * noise * inside_head
         d = np.clip(d, f32(0.0), f32(1.0))
-        out[z0:z1] = np.rint(d * f32(65535.0)).astype(np.uint16)
+        raw = np.rint(d * f32(65535.0)).astype(np.uint16)
+        if noisy_air:
+            with np.errstate(over="ignore"):
+                floor = np.uint32(64) + (wang_hash_np(np.broadcast_to(idx + np.uint32(0x9E3779B9), (nz_, ny_, nx_))) & np.uint32(127))
+            raw = np.maximum(raw, floor.astype(np.uint16))
+        out[z0:z1] = raw
     return out
 
 
@@ -246,7 +255,7 @@ def _volume(kind: str, n: int) -> Tuple[np.ndarray, float]:
             z = np.load(path)
             _VOLUME_CACHE[key] = (z["vox"], float(z["maxmag"]))
         else:
-            vox = make_sphere_volume(n) if kind == "sphere" else make_ct_head_volume(n)
+            vox = make_sphere_volume(n) if kind == "sphere" else make_ct_head_volume(n, noisy_air=(kind == "head_noisy"))
             mm = max_gradient_magnitude(vox)
             _VOLUME_CACHE[key] = (vox, mm)
             if path:
@@ -264,6 +273,10 @@ def make_scene(name: str, **overrides) -> Scene:
         "c3": ("head", 512, 1024, 1024, 3, True, True, 256, "default"),
         "c4": ("head", 512, 2048, 2048, 3, True, True, 1024, "default"),
         "c5": ("head", 1024, 1024, 1024, 3, True, True, 512, "default"),
+        # c3 / tiny_head with noisy, non-zero air: nothing is exactly transparent (see make_ct_head_volume)
+        "c3n": ("head_noisy", 512, 1024, 1024, 3, True, True, 256, "default"),
+        "tiny_head_noisy": ("head_noisy", 48, 96, 80, 3, True, True, 1, "default"),
+        "small_head_noisy": ("head_noisy", 128, 256, 256, 3, True, True, 1, "default"),
         "tiny": ("sphere", 32, 64, 64, 1, False, False, 1, "default"),
         "tiny_head": ("head", 48, 96, 80, 3, True, True, 1, "default"),
         "small_head": ("head", 128, 256, 256, 3, True, True, 1, "default"),

@@ -1,0 +1,254 @@
+"""GPU parity at the sizes of BASELINE.json's configs 2, 3 and 4 (c3, c4, c5), through the C ABI.
+
+* c3 (512^3, 1024^2) is the benchmarked configuration: the bench's exact launch shape -- the full frame, ONE
+  32-frame launch, the production (non-counting) build, group march on -- is compared with the oracle on every
+  pixel, and the cheap GPU-only property (skipping on == off == reference-shaped kernel) is checked at the same shape.
+* c4 (512^3, 2048^2): windows against the oracle, full-frame properties, 8-way row-strip composition.
+* c5 (1024^3 u16, 1024^2; the only HBM-resident volume, 16-voxel macro-cells): windows against the oracle for the
+  path tracer (with the oracle's counters) and the ray caster, skipping on == off.
+
+The oracle runs on SVR_CPU_THREADS host threads (default 16 = one GPU's CPU share of the box).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding
+from sunvolumerender_amd import abi, dist, host, scenes
+from tests.util import assert_bit_exact, oracle_frames
+
+pytestmark = pytest.mark.gpu
+THREADS = int(os.environ.get("SVR_CPU_THREADS", "0")) or min(16, os.cpu_count() or 1)
+
+
+class Rig:
+    """One canvas per configuration (the volume upload dominates the set-up), options restored after each run."""
+
+    def __init__(self, dev, name, **kw):
+        self.dev, self.sc = dev, scenes.make_scene(name, **kw)
+        self.canvas = host.Canvas(dev, self.sc.width, self.sc.height)
+        scenes.apply_to_canvas(self.sc, self.canvas)
+
+    def run(self, frames, batch=True, count=False, kernel=abi.KERNEL_AUTO, skip=1, rayskip=1, shard=None, window=None,
+            raycast=False):
+        dev, canvas = self.dev, self.canvas
+        try:
+            dev.set_option(abi.OPT_KERNEL, kernel)
+            dev.set_option(abi.OPT_EMPTY_SKIP, skip)
+            dev.set_option(abi.OPT_RAY_SKIP, rayskip)
+            dev.set_option(abi.OPT_COUNT, 1 if count else 0)
+            if shard is not None:
+                dev.check(dev.lib.svr_set_row_shard(*shard))
+            if window is not None:
+                dev.check(dev.lib.svr_set_render_window(*window))
+            dev.reset_counters()
+            # a window / shard only touches its own pixels: start from a clean accumulator and image
+            dev.check(dev.lib.svr_memset_device(canvas.renderParams.hdrBuffer, 0, self.sc.width * self.sc.height * 12))
+            dev.check(dev.lib.svr_memset_device(C.c_void_p(canvas.img), 0, self.sc.width * self.sc.height * 4))
+            canvas.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING if raycast else host.Canvas.RENDER_MODE_PATHTRACER)
+            if raycast:
+                canvas.paint()
+            elif batch:
+                canvas.paint_frames(frames)
+            else:
+                for _ in range(frames):
+                    canvas.paint()
+            dev.synchronize()
+            return canvas.read_hdr(), canvas.read_img(), dev.counters()
+        finally:
+            dev.lib.svr_set_row_shard(0, 0, 1)
+            dev.lib.svr_set_render_window(0, 0, -1, -1)
+            dev.set_option(abi.OPT_KERNEL, abi.KERNEL_AUTO)
+            dev.set_option(abi.OPT_EMPTY_SKIP, 1)
+            dev.set_option(abi.OPT_RAY_SKIP, 1)
+            dev.set_option(abi.OPT_COUNT, 0)
+            canvas.SetRenderMode(host.Canvas.RENDER_MODE_PATHTRACER)
+
+    def close(self):
+        self.canvas.close()
+
+
+def _oracle_windows(sc, wins, frames, count=False):
+    o = binding.OracleScene(sc)
+    ref = o.new_hdr()
+    img = np.zeros((o.H, o.W, 4), dtype=np.uint8)
+    total = {}
+    for f in range(frames):
+        for w in wins:
+            c = o.render_pathtracer(ref, f, window=w, img=img, count=count, nthreads=THREADS)
+            for k, v in c.items():
+                total[k] = total.get(k, 0) + v
+    return ref, img, total
+
+
+# ------------------------------------------------------------------------------------------------------------
+# c3: the benchmark's launch shape
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c3(hip_dev):
+    r = Rig(hip_dev, "c3")
+    yield r
+    r.close()
+
+
+def test_c3_bench_shape_full_frame_vs_oracle(c3):
+    """bench.py's step: c3, the whole 1024^2 frame, one 32-frame launch of the production build (no counters, every
+    early return live, group march on because the wave is full and holds 32 frames of a pixel).  Every pixel of
+    the HDR accumulator and of the RGBA8 image against the oracle (33.5 M paths, ~11 s on 16 host threads)."""
+    sc = c3.sc
+    ref_hdr, ref_img, _ = oracle_frames(sc, 32, nthreads=THREADS)
+    hdr, img, _ = c3.run(32, batch=True, count=False)
+    assert_bit_exact(hdr, ref_hdr, "c3 full frame, one 32-frame launch, production build")
+    assert np.array_equal(img, ref_img)
+    # a second group continues the running mean from frame 32 (the accumulator is read back, not cleared)
+    c3.canvas.paint_frames(32, sync=True)
+    hdr64 = c3.canvas.read_hdr()
+    o = binding.OracleScene(sc)
+    win = (448, 496, 576, 528)
+    ref64 = ref_hdr.copy()
+    for f in range(32, 64):
+        o.render_pathtracer(ref64, f, window=win, count=False, nthreads=THREADS)
+    x0, y0, x1, y1 = win
+    assert_bit_exact(hdr64[y0:y1, x0:x1], ref64[y0:y1, x0:x1], "c3 frames 32..63 continue the running mean")
+
+
+def test_c3_bench_shape_properties(c3):
+    """At the same shape (full frame, one 32-frame launch): skipping on == empty-space skipping off == whole-ray
+    skipping off == the reference-shaped one-thread-per-pixel kernel == the counting build == 32 per-frame calls
+    (frame-ahead tracing)."""
+    a, ai, _ = c3.run(32)
+    for what, kw in (("EMPTY_SKIP=0", dict(skip=0)), ("RAY_SKIP=0", dict(rayskip=0)), ("KERNEL_PIXEL", dict(kernel=abi.KERNEL_PIXEL)),
+                     ("counting build", dict(count=True)), ("32 render_pathtracer calls", dict(batch=False))):
+        b, bi, _ = c3.run(32, **kw)
+        assert_bit_exact(a, b, f"c3 32-frame launch vs {what}")
+        assert np.array_equal(ai, bi), what
+
+
+# ------------------------------------------------------------------------------------------------------------
+# c4: 512^3 volume, 2048^2 image (BASELINE config 3; tiled across 8 GPUs there)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c4(hip_dev):
+    r = Rig(hip_dev, "c4")
+    yield r
+    r.close()
+
+
+C4_WINS = [(960, 1000, 1088, 1032), (192, 1200, 320, 1216), (1800, 80, 1928, 96), (1000, 2040, 1064, 2048)]
+
+
+def test_c4_windows_vs_oracle(c4):
+    """2048^2 windows (centre, limb, background, last rows) of a 16-frame launch and of 2 per-frame calls."""
+    ref, ref_img, ref_c = _oracle_windows(c4.sc, C4_WINS, 16, count=True)
+    hdr, img, _ = c4.run(16, batch=True)
+    for (x0, y0, x1, y1) in C4_WINS:
+        assert_bit_exact(hdr[y0:y1, x0:x1], ref[y0:y1, x0:x1], f"c4 window {(x0, y0, x1, y1)}")
+        assert np.array_equal(img[y0:y1, x0:x1], ref_img[y0:y1, x0:x1])
+    # counters of the counting build over exactly the oracle's windows
+    tot = {}
+    for w in C4_WINS:
+        _, _, c = c4.run(16, batch=True, count=True, window=w)
+        for k in ("paths", "vol_taps", "woodcock_iters", "scatter_events", "shadow_walks"):
+            tot[k] = tot.get(k, 0) + c[k]
+    for k, v in tot.items():
+        assert v == ref_c[k], (k, v, ref_c[k])
+    ref2, _, _ = _oracle_windows(c4.sc, C4_WINS[:2], 2)
+    hdr2, _, _ = c4.run(2, batch=False)
+    for (x0, y0, x1, y1) in C4_WINS[:2]:
+        assert_bit_exact(hdr2[y0:y1, x0:x1], ref2[y0:y1, x0:x1], f"c4 per-frame calls, window {(x0, y0, x1, y1)}")
+
+
+def test_c4_full_frame_properties_and_8_way_strips(c4):
+    """Full 2048^2 frame: determinism, skipping on == off, and the 8 ranks' interleaved 16-row strips (each rendered
+    alone into a zeroed buffer) sum to the single-GPU frame bit for bit -- the decomposition BASELINE config 3 names."""
+    a, ai, _ = c4.run(8)
+    b, _, _ = c4.run(8)
+    assert_bit_exact(a, b, "c4 determinism")
+    d, _, _ = c4.run(8, skip=0)
+    assert_bit_exact(a, d, "c4 empty-space skipping off")
+    assert np.isfinite(a).all() and (a >= 0).all()
+    acc = np.zeros_like(a)
+    img_acc = np.zeros_like(ai)
+    for r in range(8):
+        part, pimg, c = c4.run(8, shard=(16, r, 8))
+        rows = dist.owned_rows(c4.sc.height, 16, r, 8)
+        assert c["paths"] == 8 * len(rows) * c4.sc.width
+        other = np.setdiff1d(np.arange(c4.sc.height), rows)
+        assert not part[other].any(), f"rank {r} wrote outside its strips"
+        acc += part
+        img_acc[rows] = pimg[rows]
+    assert_bit_exact(acc, a, "c4 8-rank strip sum")
+    assert np.array_equal(img_acc, ai)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# c5: 1024^3 u16 volume (2 GiB, HBM-resident), 1024^2 image (BASELINE config 4)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c5(hip_dev):
+    r = Rig(hip_dev, "c5")
+    yield r
+    r.close()
+
+
+C5_WINS = [(480, 500, 544, 516), (96, 600, 160, 608), (700, 300, 764, 308)]
+
+
+def test_c5_windows_vs_oracle(c5):
+    """Path tracer on the 1024^3 volume: windows of an 8-frame launch against the oracle, with the oracle's counters."""
+    ref, ref_img, ref_c = _oracle_windows(c5.sc, C5_WINS, 8, count=True)
+    hdr, img, _ = c5.run(8, batch=True)
+    for (x0, y0, x1, y1) in C5_WINS:
+        assert_bit_exact(hdr[y0:y1, x0:x1], ref[y0:y1, x0:x1], f"c5 window {(x0, y0, x1, y1)}")
+        assert np.array_equal(img[y0:y1, x0:x1], ref_img[y0:y1, x0:x1])
+    tot = {}
+    for w in C5_WINS:
+        part, _, c = c5.run(8, batch=True, count=True, window=w)
+        x0, y0, x1, y1 = w
+        assert_bit_exact(part[y0:y1, x0:x1], ref[y0:y1, x0:x1], f"c5 counting build, window {w}")
+        for k in ("paths", "vol_taps", "woodcock_iters", "scatter_events", "shadow_walks"):
+            tot[k] = tot.get(k, 0) + c[k]
+    for k, v in tot.items():
+        assert v == ref_c[k], (k, v, ref_c[k])
+    assert tot["vol_taps"] / tot["paths"] > 50          # the long walks of a 1024-voxel box
+
+
+def test_c5_depth2_window_vs_oracle(c5):
+    c5.canvas.SetScatterTimes(2)
+    try:
+        o = binding.OracleScene(c5.sc)
+        ref = o.new_hdr()
+        w = C5_WINS[0]
+        for f in range(4):
+            o.render_pathtracer(ref, f, trace_depth=2, window=w, count=False, nthreads=THREADS)
+        hdr, _, _ = c5.run(4, batch=True)
+        x0, y0, x1, y1 = w
+        assert_bit_exact(hdr[y0:y1, x0:x1], ref[y0:y1, x0:x1], "c5 depth 2")
+    finally:
+        c5.canvas.SetScatterTimes(1)
+
+
+def test_c5_skip_on_equals_off_and_raycaster(c5):
+    a, ai, _ = c5.run(8)
+    b, bi, _ = c5.run(8, skip=0)
+    assert_bit_exact(a, b, "c5 empty-space skipping off")
+    e, _, _ = c5.run(8, rayskip=0)
+    assert_bit_exact(a, e, "c5 whole-ray skipping off")
+    assert np.array_equal(ai, bi)
+    # ray caster: windows against the oracle (image and step count), full frame skipping on == off
+    o = binding.OracleScene(c5.sc)
+    rc_wins = [(480, 500, 544, 504), (96, 600, 160, 604)]
+    _, full, _ = c5.run(1, raycast=True)
+    steps = 0
+    for w in rc_wins:
+        ref, rc = o.render_raycasting(window=w, nthreads=THREADS)
+        x0, y0, x1, y1 = w
+        assert np.array_equal(full[y0:y1, x0:x1], ref[y0:y1, x0:x1]), f"c5 ray caster window {w}"
+        _, _, c = c5.run(1, raycast=True, count=True, window=w)
+        assert c["raycast_steps"] == rc["raycast_steps"], w
+        steps += rc["raycast_steps"]
+    assert steps > 0
+    _, noskip, _ = c5.run(1, raycast=True, skip=0)
+    assert np.array_equal(full, noskip)

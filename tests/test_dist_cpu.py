@@ -1,20 +1,20 @@
-"""N>1 path on CPU: two gloo ranks render their interleaved strips with the oracle (standing in for the GPU
-kernel, which is bit-identical to it), reduce(SUM) the HDR buffers onto rank 0, and rank 0 compares the
-assembled frame with the single-process render."""
-import os
+"""N>1 path on CPU: gloo ranks render their interleaved strips with the oracle (standing in for the GPU kernel, which
+is bit-identical to it), the frame is assembled on rank 0 with sunvolumerender_amd.dist.FrameAssembler (strip gather,
+or the reduce(SUM) of BASELINE.json's north star), and compared with the single-process render.  The protocol
+(tests/dist_worker.py) assembles twice -- after 3 and after 6 progressive frames -- so an assembly that sums in place
+into a rank's live accumulator would be caught.  tests/test_dist_gpu.py runs the same worker over libsvr_hip.so."""
 import socket
+import subprocess
 import sys
 from pathlib import Path
 
 import numpy as np
-import torch
-import torch.distributed as tdist
-import torch.multiprocessing as mp
+import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _free_port():
+def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     p = s.getsockname()[1]
@@ -22,50 +22,58 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
-    sys.path.insert(0, str(ROOT))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    tdist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import binding
-    from sunvolumerender_amd import dist, scenes
-
-    sc = scenes.make_scene("tiny_head", trace_depth=2)
-    o = binding.OracleScene(sc)
-    hdr = o.new_hdr()
-    strip = 8
-    rows = dist.owned_rows(sc.height, strip, rank, world)
-    for f in range(2):
-        # contiguous runs of owned rows -> windows
-        start = None
-        prev = None
-        for y in list(rows) + [None]:
-            if start is None:
-                start, prev = y, y
-            elif y is not None and y == prev + 1:
-                prev = y
-            else:
-                o.render_pathtracer(hdr, f, window=(0, int(start), sc.width, int(prev) + 1), nthreads=2)
-                start, prev = y, y
-    t = torch.from_numpy(hdr)
-    dist.reduce_hdr(t, dst=0)
-    if rank == 0:
-        np.save(out_path, t.numpy())
-    tdist.barrier()
-    tdist.destroy_process_group()
+def run_ranks(world, renderer, mode, out_path, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(ROOT / "tests" / "dist_worker.py"), renderer, mode, str(out_path)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT))
+    assert res.returncode == 0, f"ranks failed ({res.returncode}):\n{res.stdout[-2000:]}\n{res.stderr[-4000:]}"
 
 
-def test_two_rank_strip_sharding_matches_single_process(tmp_path):
+def reference_frames():
     sys.path.insert(0, str(ROOT))
     from oracle import binding
     from sunvolumerender_amd import scenes
-    from tests.util import assert_bit_exact
+    from tests import dist_worker
 
-    out = str(tmp_path / "assembled.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    sc = scenes.make_scene("tiny_head", trace_depth=2)
+    sc = scenes.make_scene(dist_worker.SCENE[0], trace_depth=dist_worker.SCENE[1])
     o = binding.OracleScene(sc)
     ref = o.new_hdr()
-    for f in range(2):
+    out = {}
+    for f in range(6):
         o.render_pathtracer(ref, f)
-    assert_bit_exact(np.load(out), ref, "2-rank assembled frame")
+        if f == 2:
+            out["hdr3"] = ref.copy()
+    out["hdr6"] = ref
+    out["img6"] = o.hdr_to_ldr(ref)
+    return out
+
+
+@pytest.mark.parametrize("world,mode", [(2, "gather"), (2, "reduce"), (3, "gather")])
+def test_strip_sharding_assembles_the_single_process_frame(tmp_path, world, mode):
+    from tests.util import assert_bit_exact
+
+    out = tmp_path / "assembled.npz"
+    run_ranks(world, "oracle", mode, out)
+    got, ref = np.load(out), reference_frames()
+    assert_bit_exact(got["hdr3"], ref["hdr3"], f"{world}-rank {mode}: frame assembled after 3 frames")
+    assert_bit_exact(got["hdr6"], ref["hdr6"], f"{world}-rank {mode}: frame assembled again after 6 frames")
+    assert np.array_equal(got["img6"], ref["img6"])
+
+
+def test_frame_assembler_single_process():
+    import torch
+
+    from sunvolumerender_amd import dist
+
+    H, W = 37, 5
+    hdr = torch.arange(H * W * 3, dtype=torch.float32)
+    asm = dist.FrameAssembler(H, W, 8, 0, 1)
+    assert torch.equal(asm.assemble(hdr).reshape(-1), hdr)
+    # row bookkeeping: the ranks' rows partition the frame, strips of 8 interleaved
+    for world in (2, 3, 8):
+        rows = [dist.owned_rows(H, 8, r, world) for r in range(world)]
+        assert sorted(np.concatenate(rows).tolist()) == list(range(H))
+        assert all(((r // 8) % world == q).all() for q, r in enumerate(rows))
+        assert dist.owned_row_count(H, 8, 0, world) == len(rows[0])
+    a = dist.FrameAssembler(2048, 2048, 16, 1, 8)
+    assert a.bytes_sent_per_rank() == 256 * 2048 * 12        # 6 MiB per peer, SURVEY.md 8(e)

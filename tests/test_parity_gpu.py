@@ -16,6 +16,7 @@ CASES = [
     ("tiny_head", 1, 2),
     ("tiny_head", 4, 2),
     ("tiny_bone", 6, 1),
+    ("tiny_head_noisy", 2, 2),        # non-zero air: no macro-cell is exactly transparent
 ]
 
 
@@ -45,7 +46,7 @@ def test_pathtracer_bit_exact(hip_dev, name, depth, frames, kernel, skip, kid, l
     # algorithmic taps = what the reference issues; executed taps are fewer (reused scatter tap, skipping)
     assert c["vol_taps"] == ref_c["vol_taps"]
     assert c["vol_taps_executed"] <= c["vol_taps"]
-    if kernel in (abi.KERNEL_TILE, abi.KERNEL_WAVEFRONT) and skip:
+    if kernel in (abi.KERNEL_TILE, abi.KERNEL_WAVEFRONT) and skip and not name.endswith("_noisy"):
         assert c["vol_taps_executed"] < c["vol_taps"] - ref_c["scatter_events"]
 
 

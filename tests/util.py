@@ -19,28 +19,44 @@ def oracle_frames(scene, nframes, trace_depth=None, window=None, nthreads=0):
     return hdr, img, total
 
 
-def hip_frames(dev, scene, nframes, kernel=abi.KERNEL_AUTO, layout=abi.LAYOUT_AUTO, batch=False, count=True,
+def hip_frames(dev, scene, nframes, kernel=abi.KERNEL_AUTO, layout=abi.LAYOUT_AUTO, batch=False, count=None,
                shard=None, window=None, empty_skip=True, pipeline=True):
-    """Progressive frames 0..nframes-1 through libsvr_hip.so, replaying the Canvas protocol."""
+    """Progressive frames 0..nframes-1 through libsvr_hip.so, replaying the Canvas protocol.
+
+    count=None (default) renders TWICE on the same canvas: first the production build (no counters: every early
+    return of the walk is live -- the path bench.py times), then the counting build (every iteration runs so that
+    the counters equal the oracle's); the two results must agree bit for bit, and the counting run's counters
+    are returned.  count=True / False runs one of them."""
     canvas = host.Canvas(dev, scene.width, scene.height)
     try:
         scenes.apply_to_canvas(scene, canvas, layout)
         dev.set_option(abi.OPT_KERNEL, kernel)
-        dev.set_option(abi.OPT_COUNT, 1 if count else 0)
         dev.set_option(abi.OPT_EMPTY_SKIP, 1 if empty_skip else 0)
         dev.set_option(abi.OPT_PIPELINE, 1 if pipeline else 0)
         if shard is not None:
             dev.check(dev.lib.svr_set_row_shard(*shard))
         if window is not None:
             dev.check(dev.lib.svr_set_render_window(*window))
-        dev.reset_counters()
-        if batch:
-            canvas.paint_frames(nframes)
+
+        def run(cnt):
+            dev.set_option(abi.OPT_COUNT, 1 if cnt else 0)
+            dev.reset_counters()
+            canvas.ReStartRender()
+            if batch:
+                canvas.paint_frames(nframes)
+            else:
+                for _ in range(nframes):
+                    canvas.paint()
+            dev.synchronize()
+            return canvas.read_hdr(), canvas.read_img(), dev.counters()
+
+        if count is None:
+            p_hdr, p_img, _ = run(False)
+            hdr, img, counters = run(True)
+            assert_bit_exact(p_hdr, hdr, "production (non-counting) build vs counting build")
+            assert np.array_equal(p_img, img), "production vs counting build: LDR image differs"
         else:
-            for _ in range(nframes):
-                canvas.paint()
-        dev.synchronize()
-        hdr, img, counters = canvas.read_hdr(), canvas.read_img(), dev.counters()
+            hdr, img, counters = run(bool(count))
     finally:
         dev.lib.svr_set_row_shard(0, 0, 1)
         dev.lib.svr_set_render_window(0, 0, -1, -1)

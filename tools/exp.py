@@ -23,8 +23,11 @@ a = ap.parse_args()
 
 sc = scenes.make_scene(a.scene, trace_depth=a.depth)
 dev = host.Device(0)
-dev.set_option(100, a.stop)
-dev.set_option(101, a.unit)
+if a.stop or a.unit:
+    # options 100 / 101 exist only in experiment builds:
+    #   SVR_EXTRA_HIPCC_FLAGS=-DSVR_TEST_HOOKS python -m sunvolumerender_amd._build --force
+    dev.set_option(100, a.stop)
+    dev.set_option(101, a.unit)
 dev.set_option(abi.OPT_FRAMES_PER_WAVE_LOG2, a.fl2)
 print("stop:", a.stop, "lib:", abi.library_path().name, "|", dev.info(), flush=True)
 canv = {}

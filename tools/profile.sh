@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-count --steps 4 --warmup 1 $*"
+BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-count --no-extra --steps ${PROF_STEPS:-2} --warmup 1 $*"
 echo "== trace" 
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; }
 i=0
