@@ -382,7 +382,9 @@ def main():
     # ---- secondary workloads (one GPU only): nothing skippable, so algorithmic bytes = executed bytes ----
     if world == 1 and not args.no_extra and args.scene == "c3" and args.kernel in (0, 2):
         extra = {}
-        for tag, sc_name, skip in (("c3_noisy_air", "c3n", 1), ("c3_skip_off", "c3", 0)):
+        # (the C ABI holds ONE scene per process, like the reference's __constant__ globals: the headline canvas goes
+        # first, the second canvas replaces the scene and nothing is rendered on the first one afterwards)
+        for tag, sc_name, skip in (("c3_skip_off", "c3", 0), ("c3_noisy_air", "c3n", 1)):
             w2 = wl if sc_name == args.scene else Workload(dev, torch, sc_name, args.trace_depth, args.layout)
             dev.set_option(abi.OPT_EMPTY_SKIP, skip)
             n = max(1, args.extra_steps)

@@ -21,6 +21,28 @@ def oracle():
     return binding.load()
 
 
+_HIP_DEV = []
+
+
+@pytest.fixture(autouse=True)
+def _reset_library_options():
+    """The C ABI keeps one scene and one option set per process (like the reference's globals): leave every test
+    with the defaults, whatever the previous one set."""
+    yield
+    if _HIP_DEV:
+        from sunvolumerender_amd import abi
+
+        dev = _HIP_DEV[0]
+        dev.lib.svr_clear_error()
+        dev.lib.svr_set_row_shard(0, 0, 1)
+        dev.lib.svr_set_render_window(0, 0, -1, -1)
+        for key, val in ((abi.OPT_ENV_ON_ESCAPE, 0), (abi.OPT_KERNEL, abi.KERNEL_AUTO), (abi.OPT_COUNT, 0), (abi.OPT_EMPTY_SKIP, 1),
+                         (abi.OPT_RAY_SKIP, 1), (abi.OPT_PIPELINE, 1), (abi.OPT_FRAME_AHEAD, 1), (abi.OPT_SKIP_TONEMAP, 0),
+                         (abi.OPT_FRAMES_PER_WAVE_LOG2, -1), (abi.OPT_RAYCAST_LANES_LOG2, 3)):
+            dev.lib.svr_set_option(key, val)
+        dev.lib.svr_clear_error()
+
+
 @pytest.fixture(scope="session")
 def hip_dev():
     """One HIP device context for the whole GPU test session (the C ABI keeps one scene per process)."""
@@ -28,4 +50,6 @@ def hip_dev():
 
     if not abi.library_path().exists():
         pytest.fail(f"{abi.library_path()} missing: the HIP extension must be built (no CPU fallback exists)")
-    return host.Device(0, fatal_errors=False)
+    dev = host.Device(0, fatal_errors=False)
+    _HIP_DEV.append(dev)
+    return dev

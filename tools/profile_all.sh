@@ -1,0 +1,14 @@
+#!/bin/bash
+# The three measured workloads of bench.py under rocprofv3 (kernel trace + separate PMC passes each), and the per-launch
+# PMC records bench.py reads.  Usage: tools/profile_all.sh <round-tag>   (results under gpurun_out/prof_<tag>_*)
+set -u
+R=$1
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT
+export PMC_ONLY="${PMC_ONLY:-1 2 3 4 5 6}"
+for spec in "c3_d1:--scene c3" "c3_d1_noskip:--scene c3 --empty-skip 0" "c3n_d1:--scene c3n"; do
+  tag=${spec%%:*}; args=${spec#*:}
+  echo "=== $tag ($args)"
+  PROF_STEPS=${PROF_STEPS:-1} bash tools/profile.sh ${R}_$tag $args --spp-per-step ${PROF_SPP:-64} > gpurun_out/prof_${R}_$tag.log 2>&1 || { echo "profile $tag failed"; tail -5 gpurun_out/prof_${R}_$tag.log; exit 1; }
+  python3 tools/pmc_json.py gpurun_out/prof_${R}_$tag/summary.txt "k_trace_tile" $tag gpurun_out/prof_${R}_$tag/pmc.json "bench.py $args --spp-per-step ${PROF_SPP:-64} (32 frames per launch)" | cut -c1-400
+done
