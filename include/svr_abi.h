@@ -196,6 +196,11 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
 #define SVR_OPT_RAY_SKIP 10        /* 1 (default): per-ray conservative march over the dilated empty mask: a walk that can
                                      never meet a non-transparent macro-cell ends at once when no random draw follows it,
                                      and other walks skip cell tests up to their first possibly-occupied cell (bit-identical) */
+#define SVR_OPT_BOUND_CULL 15       /* 1 (default): majorant-bound fetch culling -- a Woodcock iteration draws its accept number first and
+                                     fetches only if it is below (largest alpha reachable in the macro-cell) / sigma_max; bit-identical
+                                     results, same random-number stream (csrc/svr_accel.hip, k_bound_class) */
+#define SVR_OPT_PARK_MIN 16         /* walk loop of the tile kernel: lanes that need a fetch (or a re-march) wait until this many lanes of
+                                     the wave do, then are served together; 1..64, default 16.  Speed only */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */
@@ -226,7 +231,7 @@ typedef struct svr_counters {
     uint64_t walks_ray_skipped; /* Woodcock walks a non-counting build ends at once (whole-ray test) */
     uint64_t iters_ray_skipped; /* ... and the Woodcock iterations those walks contain */
     uint64_t iters_prefix_skipped; /* iterations before a walk's first possibly-occupied macro-cell (no cell test) */
-    uint64_t reserved;
+    uint64_t taps_bound_culled; /* fetches of non-empty cells not issued because the accept draw was above the cell's bound */
 } svr_counters;
 /* test hook: the ray caster's sample-chain replay on n items (t, h, bound, steps) -> (count <, count <=, t after steps, flags) */
 int svr_selftest_chain(const float* items, float* results, uint32_t n);

@@ -105,7 +105,7 @@ class Counters(C.Structure):  # svr_counters
         ("walks_ray_skipped", C.c_uint64),
         ("iters_ray_skipped", C.c_uint64),
         ("iters_prefix_skipped", C.c_uint64),
-        ("reserved", C.c_uint64),
+        ("taps_bound_culled", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -136,6 +136,8 @@ OPT_PIPELINE, OPT_REFILL_MIN_IDLE, OPT_EMPTY_SKIP, OPT_RAY_SKIP, OPT_FRAMES_PER_
 OPT_RAYCAST_LANES_LOG2 = 12
 OPT_FRAME_AHEAD = 13
 OPT_FAST_MATH = 14
+OPT_BOUND_CULL = 15
+OPT_PARK_MIN = 16
 KERNEL_AUTO, KERNEL_PIXEL, KERNEL_TILE, KERNEL_ULOOP, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4
 
 ELEM_I8, ELEM_U8, ELEM_I16, ELEM_U16, ELEM_I32, ELEM_U32, ELEM_F32, ELEM_F64 = range(8)

@@ -71,6 +71,80 @@ __global__ __launch_bounds__(256) void k_empty_mask(const uint16_t* __restrict__
     if (zeros == (uint32_t)(e_hi - e_lo + 1)) atomicOr(&mask[m >> 5], 1u << (m & 31u));
 }
 
+// MAJORANT-BOUND FETCH CULLING (bit-exact).  The reference's accept test is  xi < sigma_t * invSigmaMax
+// (woodcock_tracking.h:43) with sigma_t = the transfer function's alpha at the fetched intensity.  With A(m) the largest
+// alpha ANY fetch inside macro-cell m can return (k_empty_mask's argument: the LUT entries e(Imin) .. e(Imax)+1, and a
+// lerp never leaves [min, max] of its two entries), sigma_t * invSigmaMax <= A(m) * invSigmaMax =: b(m) (the same
+// float multiply, monotone).  The accept draw xi does not depend on the fetch, so a walk may draw it FIRST and fetch
+// only if xi < b(m): otherwise the test fails whatever the voxels hold.  Cells where alpha is not exactly 0 but small
+// -- noisy air in real CT data under any smooth transfer function -- then cost a fetch in a fraction b(m) of the
+// iterations instead of all of them, and every path still consumes the reference's random numbers in the
+// reference's order.  b is stored as a 4-bit class per HALF-resolution macro-cell (largest class of the 2x2x2
+// children; 16 KB in LDS): thresholds thr[0] = 0, thr[c] = 2^((c-15)/2) for c = 1..14, thr[15] = +inf (always fetch:
+// also covers a majorant that is violated, b > 1); class = the smallest c with b <= thr[c].
+__device__ inline float bound_thr(uint32_t c)
+{
+    if (c == 0u) return 0.f;
+    if (c >= BOUND_CLASSES - 1u) return u2f(SVR_INF_BITS);
+    const uint32_t k = 15u - c;                                // thr = 2^(-k/2)
+    const float p = u2f((127u - ((k + 1u) >> 1)) << 23);       // 2^-ceil(k/2)
+    return (k & 1u) ? p * 1.41421356237f : p;
+}
+
+__global__ __launch_bounds__(256) void k_bound_class(const uint16_t* __restrict__ mm, int gx, int gy, int gz, int hgx, int hgy, int hgz,
+                                                     const float* __restrict__ tf, int tf_n, float densityScale, float invSigmaMax,
+                                                     uint32_t* __restrict__ cls, float* __restrict__ thr)
+{
+    const uint32_t hq = blockIdx.x * 256u + threadIdx.x;
+    if (hq < BOUND_CLASSES) thr[hq] = bound_thr(hq);
+    const uint32_t hn = (uint32_t)hgx * (uint32_t)hgy * (uint32_t)hgz;
+    if (hq >= hn) return;
+    const int hx = (int)(hq % (uint32_t)hgx), hy = (int)((hq / (uint32_t)hgx) % (uint32_t)hgy), hz = (int)(hq / ((uint32_t)hgx * (uint32_t)hgy));
+    const float nf = (float)tf_n;
+    uint32_t c_max = 0u;
+    for (int d = 0; d < 8; ++d) {
+        const int x = 2 * hx + (d & 1), y = 2 * hy + ((d >> 1) & 1), z = 2 * hz + (d >> 2);
+        if (x >= gx || y >= gy || z >= gz) continue;
+        const size_t m = (size_t)x + (size_t)gx * ((size_t)y + (size_t)gy * (size_t)z);
+        const float rlo = (float)mm[2 * m], rhi = (float)mm[2 * m + 1];
+        float ilo = (rlo * 1.5259021896696422e-05f) * densityScale;      // the two multiplies of tex_fetch / intensity_at
+        float ihi = (rhi * 1.5259021896696422e-05f) * densityScale;
+        if (!(ilo == ilo) || !(ihi == ihi)) { c_max = BOUND_CLASSES - 1u; break; }
+        if (ihi < ilo) { float t = ilo; ilo = ihi; ihi = t; }
+        const float xl = fmin_(fmax_(fma_(ilo, nf, -0.5f), -1.f), nf);   // lds_tf_coord
+        const float xh = fmin_(fmax_(fma_(ihi, nf, -0.5f), -1.f), nf);
+        const int e_lo = (int)__builtin_floorf(xl) + 1;
+        const int e_hi = (int)__builtin_floorf(xh) + 2;
+        float amax = 0.f;
+        bool bad = false;
+        for (int e = e_lo; e <= e_hi; ++e) {                              // padded table: entry e = alpha of texel clamp(e - 1)
+            const int t = min(max(e - 1, 0), tf_n - 1);
+            const float a = tf[4 * t + 3];
+            bad = bad || !(a == a);
+            amax = fmax_(amax, a);
+        }
+        const float b = amax * invSigmaMax;                               // the product of the accept test
+        uint32_t c = BOUND_CLASSES - 1u;
+        if (!bad && b == b)
+            for (uint32_t k = 0; k < BOUND_CLASSES; ++k)
+                if (b <= bound_thr(k)) { c = k; break; }
+        c_max = max(c_max, c);
+    }
+    atomicOr(&cls[hq >> 3], c_max << ((hq & 7u) << 2));
+}
+
+hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const float* tf_rgba, int tf_n, float densityScale,
+                              float invSigmaMax, uint32_t* accel, hipStream_t st)
+{
+    const int hgx = (gx + 1) / 2, hgy = (gy + 1) / 2, hgz = (gz + 1) / 2;
+    const uint32_t hn = (uint32_t)hgx * (uint32_t)hgy * (uint32_t)hgz;
+    hipError_t e = hipMemsetAsync(accel + ACCEL_CLASS_OFF, 0, (size_t)DIST_WORDS_MAX * 4u, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bound_class, dim3((hn + 255u) / 256u), dim3(256), 0, st, mm, gx, gy, gz, hgx, hgy, hgz, tf_rgba, tf_n, densityScale,
+                       invSigmaMax, accel + ACCEL_CLASS_OFF, reinterpret_cast<float*>(accel + ACCEL_THR_OFF));
+    return hipGetLastError();
+}
+
 hipError_t launch_minmax(const uint16_t* src, uint16_t* mm, int nx, int ny, int nz, int shift,
                          int gx, int gy, int gz, hipStream_t st)
 {

@@ -109,13 +109,13 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 16;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint8_t* d_mask_tmp = nullptr;     // scratch of the distance transform
     bool mask_valid = false;
     uint64_t mask_vol = 0, mask_tf = 0, mask_tf_version = 0;
-    uint32_t mask_ds_bits = 0;
+    uint32_t mask_ds_bits = 0, mask_sigma_bits = 0;
     uint32_t mask_words = 0;
     // ring of HIP event pairs around the path-tracing kernel (SVR_OPT_TIMING); drained lazily so the
     // timed launches never synchronise with the host
@@ -193,7 +193,7 @@ int ensure_init()
     HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
     HIP_TRY(hipMalloc((void**)&g.d_ticket, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * Context::NSETS));
     HIP_TRY(hipMemset(g.d_ticket, 0, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * Context::NSETS));
-    HIP_TRY(hipMalloc((void**)&g.d_mask, (svr::DIST_WORDS_MAX + 2 * svr::MASK_WORDS_MAX) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&g.d_mask, svr::ACCEL_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&g.d_mask_tmp, 2 * (size_t)svr::MASK_WORDS_MAX * 32));
     for (int i = 0; i < Context::NSETS; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&g.sets[i].stream, hipStreamNonBlocking));
@@ -398,18 +398,21 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
     Texture* tv = find_tex(vol.tex, TEX_VOLUME);
     Texture* tt = find_tex(tf.tex, TEX_TF);
     if (!tv || !tt || !tv->mm || !tt->zero_prefix) return 0;
-    uint32_t ds_bits;
+    uint32_t ds_bits, sg_bits;
     memcpy(&ds_bits, &vol.densityScale, 4);
+    memcpy(&sg_bits, &tf.maxOpacity, 4);
     uint32_t n_cells = (uint32_t)tv->mc_gx * (uint32_t)tv->mc_gy * (uint32_t)tv->mc_gz;
     uint32_t words = (n_cells + 31u) / 32u;
     if (!(g.mask_valid && g.mask_vol == vol.tex && g.mask_tf == tf.tex && g.mask_tf_version == tt->version &&
-          g.mask_ds_bits == ds_bits)) {
+          g.mask_ds_bits == ds_bits && g.mask_sigma_bits == sg_bits)) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(svr::launch_empty_mask(tv->mm, tv->mc_gx, tv->mc_gy, tv->mc_gz, tt->zero_prefix, tt->nx,
                                        vol.densityScale, g.d_mask, words, g.d_mask_tmp, g.stream));
+        HIP_TRY(svr::launch_bound_class(tv->mm, tv->mc_gx, tv->mc_gy, tv->mc_gz, (const float*)tt->data, tt->nx, vol.densityScale,
+                                        s.invSigmaMax, g.d_mask, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
         g.mask_valid = true; g.mask_vol = vol.tex; g.mask_tf = tf.tex; g.mask_tf_version = tt->version;
-        g.mask_ds_bits = ds_bits; g.mask_words = words;
+        g.mask_ds_bits = ds_bits; g.mask_sigma_bits = sg_bits; g.mask_words = words;
     }
     s.empty_mask = g.d_mask;
     s.mask_words = g.mask_words;
@@ -437,6 +440,8 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
         inside = inside && cl >= lo[a] && ch <= hi[a] && lo[a] < hi[a];
     }
     s.ray_skip = (inside && g.opt_ray_skip) ? 1u : 0u;
+    s.bound_cull = g.opt_bound_cull ? 1u : 0u;
+    s.park_min = (uint32_t)g.opt_park_min;
     return 0;
 }
 
@@ -1004,6 +1009,10 @@ int svr_set_option(int key, int value)
     case SVR_OPT_PIPELINE: g.opt_pipeline = value ? 1 : 0; return 0;
     case SVR_OPT_EMPTY_SKIP: g.opt_empty_skip = value ? 1 : 0; return 0;
     case SVR_OPT_RAY_SKIP: g.opt_ray_skip = value ? 1 : 0; return 0;
+    case SVR_OPT_BOUND_CULL: g.opt_bound_cull = value ? 1 : 0; return 0;
+    case SVR_OPT_PARK_MIN:
+        if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_MIN: bad value %d (1..64)", value);
+        g.opt_park_min = value; return 0;
 #ifdef SVR_TEST_HOOKS
     // experiment builds only (tools/exp.py; `SVR_EXTRA_HIPCC_FLAGS=-DSVR_TEST_HOOKS python -m sunvolumerender_amd._build --force`)
     case 100: g.opt_debug_stop = value; return 0;      // timing ablation: stop every path after a phase (wrong images)
@@ -1035,6 +1044,8 @@ int svr_get_option(int key)
     case SVR_OPT_PIPELINE: return g.opt_pipeline;
     case SVR_OPT_EMPTY_SKIP: return g.opt_empty_skip;
     case SVR_OPT_RAY_SKIP: return g.opt_ray_skip;
+    case SVR_OPT_BOUND_CULL: return g.opt_bound_cull;
+    case SVR_OPT_PARK_MIN: return g.opt_park_min;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     case SVR_OPT_FRAMES_PER_WAVE_LOG2: return g.opt_frames_log2;
     case SVR_OPT_RAYCAST_LANES_LOG2: return g.opt_rc_lanes;

@@ -98,7 +98,7 @@ SVR_DEV unsigned long long wave_sum(unsigned long long v)
     return v;
 }
 
-struct Cnt { uint32_t taps, iters, scatter, shadow, paths, loops, exec, wskip, iskip, ipre; };
+struct Cnt { uint32_t taps, iters, scatter, shadow, paths, loops, exec, wskip, iskip, ipre, cull; };
 
 SVR_DEV void cnt_flush(const DevWork& w, const Cnt& c)
 {
@@ -113,11 +113,12 @@ SVR_DEV void cnt_flush(const DevWork& w, const Cnt& c)
         atomicAdd(&w.counters[CNT_LOOP], (unsigned long long)c.loops);
         atomicAdd(&w.counters[CNT_TAPS_EXEC], x);
     }
-    unsigned long long ws = wave_sum(c.wskip), is = wave_sum(c.iskip), ip = wave_sum(c.ipre);
+    unsigned long long ws = wave_sum(c.wskip), is = wave_sum(c.iskip), ip = wave_sum(c.ipre), cu = wave_sum(c.cull);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&w.counters[CNT_WALKS_RAYSKIP], ws);
         atomicAdd(&w.counters[CNT_ITERS_RAYSKIP], is);
         atomicAdd(&w.counters[CNT_ITERS_PREFIX], ip);
+        atomicAdd(&w.counters[CNT_CULLED], cu);
     }
 }
 

@@ -13,10 +13,16 @@ constexpr uint32_t TICKET_STRIDE = 32;      // in uint32 words
 constexpr uint32_t MASK_WORDS_MAX = 8192;   // words of the LDS-resident `empty` bitmask (32 KiB): up to 64^3 macro-cells
 constexpr uint32_t DIST_WORDS_MAX = 4096;   // words of the half-resolution 4-bit distance field (16 KiB): up to 32^3 coarse cells
 constexpr int DIST_CAP = 15;
+// Bound classes (svr_accel.hip, k_bound_class): 4 bits per half-resolution macro-cell = smallest class c whose threshold
+// BOUND_THR(c) is >= (largest transfer-function alpha any fetch in the cell can return) x invSigmaMax.
+constexpr uint32_t BOUND_CLASSES = 16;
+constexpr uint32_t ACCEL_WORDS = DIST_WORDS_MAX + 2 * MASK_WORDS_MAX + DIST_WORDS_MAX + BOUND_CLASSES;   // device buffer: dist | deep | empty | class | thresholds
+constexpr uint32_t ACCEL_CLASS_OFF = DIST_WORDS_MAX + 2 * MASK_WORDS_MAX;
+constexpr uint32_t ACCEL_THR_OFF = ACCEL_CLASS_OFF + DIST_WORDS_MAX;
 
 // counter slots (unsigned long long each) -- order of svr_counters in include/svr_abi.h
 enum { CNT_PATHS = 0, CNT_VOL_TAPS, CNT_WOODCOCK, CNT_SCATTER, CNT_SHADOW, CNT_RAYCAST, CNT_LOOP, CNT_TAPS_EXEC,
-       CNT_WALKS_RAYSKIP, CNT_ITERS_RAYSKIP, CNT_ITERS_PREFIX, CNT_RESERVED, CNT_N };
+       CNT_WALKS_RAYSKIP, CNT_ITERS_RAYSKIP, CNT_ITERS_PREFIX, CNT_CULLED, CNT_N };
 
 struct LaunchCfg {
     int kernel;            // KERNEL_*
@@ -45,6 +51,9 @@ hipError_t launch_minmax(const uint16_t* src_linear, uint16_t* mm, int nx, int n
 // bits; tmp: 2 * gx*gy*gz bytes of scratch
 hipError_t launch_empty_mask(const uint16_t* mm, int gx, int gy, int gz, const uint32_t* tf_zero_prefix, int tf_n,
                              float densityScale, uint32_t* mask, uint32_t mask_words, uint8_t* tmp, hipStream_t stream);
+// bound classes of the half-resolution macro-cells (4 bit each) + the BOUND_CLASSES thresholds, into accel + ACCEL_CLASS_OFF
+hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const float* tf_rgba, int tf_n, float densityScale,
+                              float invSigmaMax, uint32_t* accel, hipStream_t stream);
 // hdr_to_ldr over the owned pixels
 hipError_t launch_tonemap(const DevScene& scene, const DevWork& work, hipStream_t stream);
 // self-test of the ray caster's sample-chain replay (tests only): in = (t, h, bound, n) per item

@@ -46,6 +46,8 @@ struct DevScene {
     int32_t mc_hgx, mc_hgxy;       // half-resolution grid of the distance field: row and slice strides
     uint32_t mask_words, dist_words;
     uint32_t ray_skip;             // 1: the clipped box lies inside the texture domain, so whole-ray tests are valid
+    uint32_t bound_cull;           // 1: the bound-class table behind the masks is valid (majorant-bound fetch culling)
+    uint32_t park_min;             // walk loop: lanes waiting for a fetch / a re-march before the wave serves them
     float mc_scale[3];             // macro-grid coordinate = (p - vmin) * mc_scale + mc_off
     float mc_off;
     // ---- cudaTransferFunction ----

@@ -149,7 +149,7 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
 template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1>
 __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_trace_tile(const DevScene s, const DevWork w)
 {
-    using LDS = typename std::conditional<SKIP, LdsTile, LdsTileNoMask>::type;
+    using LDS = typename std::conditional<SKIP, LdsTileCull, LdsTileNoMask>::type;
     __shared__ LDS lds;
     lds_tile_load(lds, s, SKIP);
 

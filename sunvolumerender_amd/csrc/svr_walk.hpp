@@ -18,6 +18,13 @@ struct LdsTileNoMask {
     uint32_t mask[1];
     uint32_t emask[1];
 };
+// LdsTile + the bound classes of the half-resolution macro-cells (svr_accel.hip, k_bound_class): the tile kernel
+struct LdsTileCull : LdsTile {
+    uint32_t cls[DIST_WORDS_MAX];              // 4 bits per half-resolution macro-cell
+    float thr[BOUND_CLASSES];                  // class -> threshold on the accept draw
+};
+template <typename LDS> struct lds_has_cull { static constexpr bool value = false; };
+template <> struct lds_has_cull<LdsTileCull> { static constexpr bool value = true; };
 
 template <typename LDS>
 SVR_DEV void lds_tile_load(LDS& L, const DevScene& s, bool with_mask)
@@ -37,6 +44,12 @@ SVR_DEV void lds_tile_load(LDS& L, const DevScene& s, bool with_mask)
         const uint4* src2 = reinterpret_cast<const uint4*>(s.empty_mask + DIST_WORDS_MAX + MASK_WORDS_MAX);
         uint4* dst2 = reinterpret_cast<uint4*>(L.emask);
         for (uint32_t q = threadIdx.x; q < (s.mask_words + 3u) / 4u; q += blockDim.x) dst2[q] = src2[q];
+        if constexpr (lds_has_cull<LDS>::value) {
+            const uint4* src3 = reinterpret_cast<const uint4*>(s.empty_mask + ACCEL_CLASS_OFF);
+            uint4* dst3 = reinterpret_cast<uint4*>(L.cls);
+            for (uint32_t q = threadIdx.x; q < (s.dist_words + 3u) / 4u; q += blockDim.x) dst3[q] = src3[q];
+            if (threadIdx.x < BOUND_CLASSES) L.thr[threadIdx.x] = reinterpret_cast<const float*>(s.empty_mask + ACCEL_THR_OFF)[threadIdx.x];
+        }
     }
     __syncthreads();
 }
@@ -142,6 +155,35 @@ SVR_DEV bool cell_is_empty(const LDS& L, const DevScene& s, const Cell& c)
     m = inb ? m : 0u;
     uint32_t word = DEEP ? L.mask[m >> 5] : L.emask[m >> 5];
     return inb && ((word >> (m & 31u)) & 1u);
+}
+
+// One look at the macro grid for a trilinear cell: CELL_EMPTY (no fetch can return a non-zero opacity), CELL_DEEP
+// (so are the 26 neighbours), and the bound on the accept draw below which a fetch is needed at all (+inf outside
+// the grid and when culling is off).
+struct CellInfo { bool empty, deep; float thr; };
+template <bool WANT_DEEP, typename LDS>
+SVR_DEV CellInfo cell_info(const LDS& L, const DevScene& s, const Cell& c)
+{
+    const uint32_t ux = (uint32_t)(c.cx + 1), uy = (uint32_t)(c.cy + 1), uz = (uint32_t)(c.cz + 1);
+    const bool inb = (ux <= (uint32_t)s.nx) & (uy <= (uint32_t)s.ny) & (uz <= (uint32_t)s.nz);
+    const uint32_t sh = (uint32_t)s.mc_shift;
+    const uint32_t qx = min(ux >> sh, (uint32_t)s.mc_gx - 1u), qy = min(uy >> sh, (uint32_t)s.mc_gy - 1u),
+                   qz = min(uz >> sh, (uint32_t)s.mc_gz - 1u);
+    uint32_t m = qx + __umul24(qy, (uint32_t)s.mc_gx) + __umul24(qz, (uint32_t)s.mc_gxy);
+    m = inb ? m : 0u;
+    CellInfo r;
+    r.empty = inb && ((L.emask[m >> 5] >> (m & 31u)) & 1u);
+    r.deep = WANT_DEEP ? (inb && ((L.mask[m >> 5] >> (m & 31u)) & 1u)) : false;
+    r.thr = u2f(SVR_INF_BITS);
+    if constexpr (lds_has_cull<LDS>::value) {
+        if (s.bound_cull) {
+            uint32_t hq = (qx >> 1) + __umul24(qy >> 1, (uint32_t)s.mc_hgx) + __umul24(qz >> 1, (uint32_t)s.mc_hgxy);
+            hq = inb ? hq : 0u;
+            const uint32_t cl = (L.cls[hq >> 3] >> ((hq & 7u) << 2)) & 15u;
+            r.thr = inb ? L.thr[cl] : u2f(SVR_INF_BITS);
+        }
+    }
+    return r;
 }
 
 // Conservative march of the ray segment [t0, t1] through the macro grid: returns a ray parameter before which
@@ -318,88 +360,97 @@ SVR_DEV int walk_setup_group(const DevScene& s, const LDS& L, uint32_t P2, v3 or
     return hit ? 1 : -1;
 }
 
-// REMARCH: a walk that comes out of an occupied stretch into clear space (two consecutive iterations in
-// deep-empty cells) PARKS: it leaves the iteration loop.  The lanes of a wave reconverge at the loop exit, so the
-// parked lanes march again TOGETHER (a per-lane march inside the loop is serialised by divergence and was
-// slower than not marching at all).  If nothing occupied lies ahead and no draw follows the walk, its result
-// (-FLT_MAX) is known; otherwise it resumes with the new t_occ.  COUNT builds keep iterating instead so that
-// the iteration/tap counters stay the reference's.
-// MAP: the walk belongs to a pixel group with a GroupMap (primary walks of frame-major launches): an iteration that
-// lands in an empty cell asks the map for the next possibly-occupied stretch and, if that lies ahead, goes back to
-// fetch-free iterations until then (or ends, if nothing lies ahead and no draw follows the walk).
+// The walk loop.  Every iteration of the reference (woodcock_tracking.h:32-45) is: distance draw + log + advance, the
+// exit test, one fetch, the accept draw + test.  Here a lane's iteration is one of
+//   * FREE    t < t_occ (before the first possibly-occupied macro-cell, whole-ray march): no cell test, no fetch;
+//   * EMPTY   the trilinear cell lies in an `empty` macro-cell: sigma_t = 0, the accept test cannot pass;
+//   * CULLED  the accept draw is not below the cell's bound (majorant-bound culling, svr_accel.hip): cannot pass;
+//   * FETCH   everything else: 8 voxels, filter, LUT.
+// The first three cost ~50 vector instructions and no memory access; FETCH costs ~150 and eight gathers, and a wave
+// pays for it whenever ONE of its lanes needs it.  So lanes that need a fetch PARK: they stop iterating, keep their
+// accept draw, and the wave serves them together once s.park_min lanes wait (or nobody else can run); the same
+// for the wave-synchronous re-march of lanes that have left an occupied stretch (REMARCH: two consecutive
+// iterations in deep-empty cells; the march says where the next possibly-occupied cell is, or that the walk is
+// over if no draw follows it).  All of it is scheduling: each lane executes the reference's iterations in the
+// reference's order and consumes the reference's random numbers.  COUNT builds run every iteration (a walk a
+// production build would have ended keeps going) so that the iteration / tap counters stay the reference's.
+// MAP: the walk belongs to a pixel group with a GroupMap (primary walks of frame-major launches): an iteration in
+// an empty cell asks the map for the next possibly-occupied stretch and goes back to FREE iterations until then.
 template <int LAYOUT, bool COUNT, bool SKIP, bool REMARCH, bool MAP, typename LDS>
 SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float tMin, float tMax, float t_occ,
                        float& val, bool rng_live, Cnt& c, const GroupMap* map = nullptr, uint32_t P2 = 0u)
 {
-    float t = tMin;
-    const bool ray_skippable = SKIP && s.ray_skip && !rng_live && t_occ == u2f(SVR_INF_BITS);
+    enum : uint32_t { RUN = 0u, NEED_FETCH = 1u, NEED_MARCH = 2u, DONE = 3u };
+    const float INF = u2f(SVR_INF_BITS);
+    float t = tMin, result = -SVR_FLT_MAX, xi = 0.f;
+    const bool ray_skippable = SKIP && s.ray_skip && !rng_live && t_occ == INF;
     if (COUNT && ray_skippable) c.wskip++;
-    bool tail_counted = false;          // COUNT builds only: a non-counting build would have ended the walk
-    uint32_t guard = 0;
+    bool tail_counted = false;          // COUNT builds only: a production build would have ended the walk
+    uint32_t st = RUN, clear_run = 0u, guard = 0u;
+    const uint32_t park_min = s.park_min;
     for (;;) {
-        // ---- prefix: iterations before the first possibly-occupied macro-cell.  No fetch, sigma_t = 0: each is a
-        //      distance draw + log, the exit test, and the state update of the accept draw (its value is unused) ----
-        bool pending = false;           // t has been advanced and still needs its tap and accept draw
-        if (SKIP) {
-            for (;;) {
-                if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; else c.ipre++; }
-                t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-                if (t > tMax || guard++ >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
-                if (COUNT) c.taps++;
-                if (t >= t_occ) { pending = true; if (COUNT) { c.ipre -= !(ray_skippable || tail_counted); } break; }
-                rng_skip(rng);
-            }
-        }
-        // ---- general iterations (loop rotated: tap first, then advance) ----
-        uint32_t clear_run = 0;
+        // ---- cheap phase: FREE / EMPTY / CULLED iterations; lanes drop out as they finish or need service ----
         for (;;) {
-            if (!pending) {
-                if (COUNT) { c.iters++; if (tail_counted) c.iskip++; }
+            if (st == RUN) {
+                if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; }
                 t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-                if (t > tMax || guard++ >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
-                if (COUNT) c.taps++;
-            }
-            pending = false;
-            float sigma_t = 0.f;
-            bool park_now = false;
-            if (!MAP || t >= t_occ) {
-                v3 p = orig + dir * t;
-                Cell cell = cell_of(s, p);
-                bool fetch = true;
-                if (SKIP) fetch = !cell_is_empty<false>(L, s, cell);
-                if (fetch) {
-                    if (COUNT) c.exec++;
-                    val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
-                    sigma_t = alpha_of(L, s, val);
-                    clear_run = 0;
-                } else if (SKIP && MAP) {
-                    if (map->valid) {
-                        t_occ = group_map_next(*map, P2, t);          // <= t while the walk is in or next to an occupied stretch
-                        if (t_occ == u2f(SVR_INF_BITS) && !rng_live) {
-                            if (!COUNT) {
-                                // consume nothing further: the walk cannot collide any more and no draw follows it
-                                return -SVR_FLT_MAX;
+                if (t > tMax || guard++ >= SVR_WALK_GUARD) st = DONE;
+                else {
+                    if (COUNT) c.taps++;
+                    if (SKIP && t < t_occ) {
+                        if (COUNT && !(ray_skippable || tail_counted)) c.ipre++;
+                        rng_skip(rng);                                  // the accept draw of a FREE iteration
+                    } else {
+                        const Cell cell = cell_of(s, orig + dir * t);
+                        CellInfo ci;
+                        ci.empty = false; ci.deep = false; ci.thr = INF;
+                        if (SKIP) ci = cell_info<REMARCH && !MAP>(L, s, cell);
+                        if (ci.empty) {
+                            rng_skip(rng);                              // sigma_t = 0: the draw is consumed, the test fails
+                            if (MAP) {
+                                if (map->valid) {
+                                    t_occ = group_map_next(*map, P2, t);      // <= t while the walk is in or next to an occupied stretch
+                                    if (t_occ == INF && !rng_live) {
+                                        if (!COUNT) st = DONE;                // nothing ahead and no draw follows the walk
+                                        else if (!tail_counted) { tail_counted = true; c.wskip++; }
+                                    }
+                                }
+                            } else if (REMARCH) {
+                                clear_run = ci.deep ? clear_run + 1u : 0u;
+                                if (clear_run == 2u) st = NEED_MARCH;
                             }
-                            if (!tail_counted) { tail_counted = true; c.wskip++; }
+                        } else {
+                            clear_run = 0u;
+                            xi = rng_uniform(rng);
+                            if (xi < ci.thr) st = NEED_FETCH;          // else CULLED: xi >= bound >= sigma_t * invSigmaMax
+                            else if (COUNT) c.cull++;
                         }
                     }
-                } else if (SKIP && REMARCH) {
-                    // park after two consecutive iterations in DEEP-empty cells (where a march can start)
-                    clear_run = cell_is_empty<true>(L, s, cell) ? clear_run + 1u : 0u;
-                    park_now = clear_run == 2u;
                 }
             }
-            // the accept draw is consumed either way; with sigma_t == 0 it cannot accept (xi > 0)
-            if (rng_uniform(rng) < sigma_t * s.invSigmaMax) return t;
-            if (park_now) break;
+            const uint64_t running = __ballot(st == RUN);
+            if (running == 0ull) break;
+            if ((uint32_t)__popcll(__ballot(st == NEED_FETCH || st == NEED_MARCH)) >= park_min) break;
         }
-        // ---- parked lanes of the wave march together ----
-        t_occ = first_occupied(s, L, orig, dir, t, tMax);
-        if (t_occ == u2f(SVR_INF_BITS) && !rng_live) {
-            if (!COUNT) return -SVR_FLT_MAX;
-            if (!tail_counted) { tail_counted = true; c.wskip++; }
+        // ---- service phase ----
+        if (st == NEED_FETCH) {
+            if (COUNT) c.exec++;
+            val = tex_fetch<LAYOUT>(s, cell_of(s, orig + dir * t)) * s.densityScale;
+            const float sigma_t = alpha_of(L, s, val);
+            if (xi < sigma_t * s.invSigmaMax) { st = DONE; result = t; }
+            else st = RUN;
+        } else if (SKIP && REMARCH && !MAP && st == NEED_MARCH) {
+            t_occ = first_occupied(s, L, orig, dir, t, tMax);
+            clear_run = 0u;
+            st = RUN;
+            if (t_occ == INF && !rng_live) {
+                if (!COUNT) st = DONE;
+                else if (!tail_counted) { tail_counted = true; c.wskip++; }
+            }
         }
+        if (__ballot(st != DONE) == 0ull) break;
     }
+    return result;
 }
 
 // sample_distance in one piece (tile kernel)
