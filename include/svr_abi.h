@@ -196,11 +196,14 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
 #define SVR_OPT_RAY_SKIP 10        /* 1 (default): per-ray conservative march over the dilated empty mask: a walk that can
                                      never meet a non-transparent macro-cell ends at once when no random draw follows it,
                                      and other walks skip cell tests up to their first possibly-occupied cell (bit-identical) */
-#define SVR_OPT_BOUND_CULL 15       /* 1 (default): majorant-bound fetch culling -- a Woodcock iteration draws its accept number first and
+#define SVR_OPT_BOUND_CULL 15       /* 0 off, 1 (default) where it pays (>= 2 % of the occupied coarse macro-cells have a bound below 1), 2 always:
+                                     majorant-bound fetch culling -- a Woodcock iteration draws its accept number first and
                                      fetches only if it is below (largest alpha reachable in the macro-cell) / sigma_max; bit-identical
                                      results, same random-number stream (csrc/svr_accel.hip, k_bound_class) */
 #define SVR_OPT_PARK_MIN 16         /* walk loop of the tile kernel: lanes that need a fetch (or a re-march) wait until this many lanes of
                                      the wave do, then are served together; 1..64, default 16.  Speed only */
+#define SVR_OPT_FOLD 17             /* 1 (default): a many-frame launch of the tile kernel folds its frames into the HDR accumulator itself (running
+                                     mean in frame order, in the wave that traced them); 0: scratch slot per frame + resolve kernel */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */

@@ -93,7 +93,7 @@ __device__ inline float bound_thr(uint32_t c)
 
 __global__ __launch_bounds__(256) void k_bound_class(const uint16_t* __restrict__ mm, int gx, int gy, int gz, int hgx, int hgy, int hgz,
                                                      const float* __restrict__ tf, int tf_n, float densityScale, float invSigmaMax,
-                                                     uint32_t* __restrict__ cls, float* __restrict__ thr)
+                                                     uint32_t* __restrict__ cls, float* __restrict__ thr, uint32_t* __restrict__ census)
 {
     const uint32_t hq = blockIdx.x * 256u + threadIdx.x;
     if (hq < BOUND_CLASSES) thr[hq] = bound_thr(hq);
@@ -131,6 +131,12 @@ __global__ __launch_bounds__(256) void k_bound_class(const uint16_t* __restrict_
         c_max = max(c_max, c);
     }
     atomicOr(&cls[hq >> 3], c_max << ((hq & 7u) << 2));
+    // census (wave-aggregated): where would the bound test ever reject a fetch?
+    const uint64_t partial = __ballot(c_max >= 1u && c_max < BOUND_CLASSES - 1u), full = __ballot(c_max == BOUND_CLASSES - 1u);
+    if ((threadIdx.x & 63u) == 0u) {
+        if (partial) atomicAdd(&census[0], (uint32_t)__popcll(partial));
+        if (full) atomicAdd(&census[1], (uint32_t)__popcll(full));
+    }
 }
 
 hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const float* tf_rgba, int tf_n, float densityScale,
@@ -138,10 +144,10 @@ hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const 
 {
     const int hgx = (gx + 1) / 2, hgy = (gy + 1) / 2, hgz = (gz + 1) / 2;
     const uint32_t hn = (uint32_t)hgx * (uint32_t)hgy * (uint32_t)hgz;
-    hipError_t e = hipMemsetAsync(accel + ACCEL_CLASS_OFF, 0, (size_t)DIST_WORDS_MAX * 4u, st);
+    hipError_t e = hipMemsetAsync(accel + ACCEL_CLASS_OFF, 0, (size_t)(DIST_WORDS_MAX + BOUND_CLASSES + 2u) * 4u, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_bound_class, dim3((hn + 255u) / 256u), dim3(256), 0, st, mm, gx, gy, gz, hgx, hgy, hgz, tf_rgba, tf_n, densityScale,
-                       invSigmaMax, accel + ACCEL_CLASS_OFF, reinterpret_cast<float*>(accel + ACCEL_THR_OFF));
+                       invSigmaMax, accel + ACCEL_CLASS_OFF, reinterpret_cast<float*>(accel + ACCEL_THR_OFF), accel + ACCEL_CENSUS_OFF);
     return hipGetLastError();
 }
 

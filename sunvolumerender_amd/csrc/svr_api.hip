@@ -109,13 +109,14 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 16;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 16, opt_fold = 1;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint8_t* d_mask_tmp = nullptr;     // scratch of the distance transform
     bool mask_valid = false;
     uint64_t mask_vol = 0, mask_tf = 0, mask_tf_version = 0;
     uint32_t mask_ds_bits = 0, mask_sigma_bits = 0;
+    bool mask_cull_useful = false;
     uint32_t mask_words = 0;
     // ring of HIP event pairs around the path-tracing kernel (SVR_OPT_TIMING); drained lazily so the
     // timed launches never synchronise with the host
@@ -191,8 +192,8 @@ int ensure_init()
     g.info = buf;
     HIP_TRY(hipMalloc((void**)&g.d_counters, sizeof(svr_counters)));
     HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
-    HIP_TRY(hipMalloc((void**)&g.d_ticket, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * Context::NSETS));
-    HIP_TRY(hipMemset(g.d_ticket, 0, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * Context::NSETS));
+    HIP_TRY(hipMalloc((void**)&g.d_ticket, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * (Context::NSETS + 1)));
+    HIP_TRY(hipMemset(g.d_ticket, 0, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * (Context::NSETS + 1)));
     HIP_TRY(hipMalloc((void**)&g.d_mask, svr::ACCEL_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&g.d_mask_tmp, 2 * (size_t)svr::MASK_WORDS_MAX * 32));
     for (int i = 0; i < Context::NSETS; ++i) {
@@ -411,6 +412,11 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
         HIP_TRY(svr::launch_bound_class(tv->mm, tv->mc_gx, tv->mc_gy, tv->mc_gz, (const float*)tt->data, tt->nx, vol.densityScale,
                                         s.invSigmaMax, g.d_mask, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
+        // the bound test costs two dependent LDS reads per tested cell (4 % on a scene where it never rejects anything): use
+        // it where at least 2 % of the coarse cells that can hold a collision have a bound below 1
+        uint32_t census[2] = {0u, 0u};
+        HIP_TRY(hipMemcpy(census, g.d_mask + svr::ACCEL_CENSUS_OFF, sizeof census, hipMemcpyDeviceToHost));
+        g.mask_cull_useful = (uint64_t)census[0] * 50u >= (uint64_t)census[0] + census[1] && census[0] != 0u;
         g.mask_valid = true; g.mask_vol = vol.tex; g.mask_tf = tf.tex; g.mask_tf_version = tt->version;
         g.mask_ds_bits = ds_bits; g.mask_sigma_bits = sg_bits; g.mask_words = words;
     }
@@ -440,7 +446,7 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
         inside = inside && cl >= lo[a] && ch <= hi[a] && lo[a] < hi[a];
     }
     s.ray_skip = (inside && g.opt_ray_skip) ? 1u : 0u;
-    s.bound_cull = g.opt_bound_cull ? 1u : 0u;
+    s.bound_cull = (g.opt_bound_cull == 2 || (g.opt_bound_cull == 1 && g.mask_cull_useful)) ? 1u : 0u;
     s.park_min = (uint32_t)g.opt_park_min;
     return 0;
 }
@@ -491,7 +497,6 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     if (build_scene(g.vol, g.tf, g.cam, s)) return g.err_code;
     if (add_lights_env(s)) return g.err_code;
     if ((size_t)3 * s.imageW * s.imageH >= ((size_t)1 << 32)) return fail(-3, "image too large");
-    if (ensure_slots(s.imageW, s.imageH, nframes < (uint32_t)Context::GROUP ? nframes : (uint32_t)Context::GROUP)) return g.err_code;
     // clear_hdr_buffer zeroes the WHOLE accumulator at frame 0 (pathtracer.cu:86-94,297-300); under a row shard or a
     // window the kernels only touch their own pixels, so the rest is cleared here (the strips of the ranks are then
     // summed into one frame: stale values outside the owned rows would corrupt it)
@@ -509,6 +514,44 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     cfg.blocks_per_cu = g.opt_blocks_per_cu > 0 ? g.opt_blocks_per_cu : 4;
     cfg.frames_log2 = g.opt_frames_log2;
     cfg.unit_override = g.opt_unit;
+    // The tile kernel folds the frames of a launch into the accumulator itself (running mean in frame order, 12 B per
+    // pixel per launch, svr_trace_tile.hip); the scratch slots + k_resolve remain for frames traced AHEAD of the calls
+    // that ask for them (their radiance is folded later, one frame per call) and for the other kernels.
+    const bool fold_batch = cfg.kernel == svr::KERNEL_TILE && g.opt_fold && !g.opt_debug_stop && cfg.frames_log2 < 0;
+    const bool frame_ahead_call = nframes == 1 && g.opt_frame_ahead && g.opt_pipeline && !g.opt_count && !g.opt_debug_stop && cfg.kernel == svr::KERNEL_TILE;
+    // short launches (< FOLD_MIN frames) keep the slots: they end in a tail of a few long tasks that only overlapping launches
+    // on several streams hide, and a folding launch cannot overlap its predecessor (measured, 1 frame per call: 0.276 vs 0.366 ms)
+    constexpr uint32_t FOLD_MIN = 8;
+    const uint32_t tail_frames = nframes % (uint32_t)Context::GROUP;
+    if ((!fold_batch || frame_ahead_call || (tail_frames != 0 && tail_frames < FOLD_MIN)) &&
+        ensure_slots(s.imageW, s.imageH, nframes < (uint32_t)Context::GROUP ? nframes : (uint32_t)Context::GROUP)) return g.err_code;
+    // one folding launch: trace + accumulate on the caller's stream (the launches of a render update the same accumulator,
+    // so they run in order anyway), tone map behind the last one
+    auto trace_fold = [&](uint32_t first, uint32_t n, bool want_img) -> int {
+        svr::DevWork w;
+        fill_work(w, s.imageW, s.imageH);
+        w.hdr = (float*)rp->hdrBuffer;
+        w.img = want_img ? (uint8_t*)img : nullptr;
+        w.ticket = g.d_ticket + (size_t)svr::TICKET_SHARDS * svr::TICKET_STRIDE * Context::NSETS;   // (the sets' own counters may be in use by frames traced ahead)
+        w.traceDepth = rp->traceDepth;
+        w.frame0 = first;
+        w.nframes = n;
+        w.fold = 1u;
+        int slot = -1;
+        if (g.opt_timing) {
+            if (g.ev_count == Context::EV_RING) collect_timing();
+            slot = g.ev_head;
+            HIP_TRY(hipEventRecord(g.ev0[slot], g.stream));
+        }
+        HIP_TRY(svr::launch_trace_tile(s, w, cfg, g.stream));
+        if (g.opt_timing) {
+            HIP_TRY(hipEventRecord(g.ev1[slot], g.stream));
+            g.ev_head = (g.ev_head + 1) % Context::EV_RING;
+            g.ev_count++;
+        }
+        if (want_img) HIP_TRY(svr::launch_tonemap(s, w, g.stream));
+        return 0;
+    };
     // one trace launch of n_trace frames starting at frame `first` into scratch set `si`, then the resolve of its
     // first n_resolve frames
     auto trace_group = [&](int si, uint32_t first, uint32_t n_trace, uint32_t n_resolve, bool want_img) -> int {
@@ -576,7 +619,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     // (1, 2, 4 ... GROUP), so a host that restarts the render on every mouse event never traces more than twice what
     // it shows.  Anything that could change a frame -- scene PODs, texture contents, window, shard, trace depth --
     // invalidates the frames in stock.
-    if (nframes == 1 && g.opt_frame_ahead && g.opt_pipeline && !g.opt_count && !g.opt_debug_stop && cfg.kernel == svr::KERNEL_TILE) {
+    if (frame_ahead_call) {
         const uint32_t n = rp->frameNo;
         svr::DevWork shape;
         fill_work(shape, s.imageW, s.imageH);
@@ -619,7 +662,9 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     for (uint32_t g0 = 0; g0 < nframes; g0 += Context::GROUP) {
         uint32_t n = nframes - g0 < (uint32_t)Context::GROUP ? nframes - g0 : (uint32_t)Context::GROUP;
         bool last = g0 + n >= nframes;
-        if (trace_group(next_set(), rp->frameNo + g0, n, n, want_img && last)) return g.err_code;
+        if (fold_batch && n >= FOLD_MIN) {
+            if (trace_fold(rp->frameNo + g0, n, want_img && last)) return g.err_code;
+        } else if (trace_group(next_set(), rp->frameNo + g0, n, n, want_img && last)) return g.err_code;
     }
     return 0;
 }
@@ -1009,7 +1054,10 @@ int svr_set_option(int key, int value)
     case SVR_OPT_PIPELINE: g.opt_pipeline = value ? 1 : 0; return 0;
     case SVR_OPT_EMPTY_SKIP: g.opt_empty_skip = value ? 1 : 0; return 0;
     case SVR_OPT_RAY_SKIP: g.opt_ray_skip = value ? 1 : 0; return 0;
-    case SVR_OPT_BOUND_CULL: g.opt_bound_cull = value ? 1 : 0; return 0;
+    case SVR_OPT_BOUND_CULL:
+        if (value < 0 || value > 2) return fail(-6, "SVR_OPT_BOUND_CULL: bad value %d (0 off, 1 auto, 2 always)", value);
+        g.opt_bound_cull = value; return 0;
+    case SVR_OPT_FOLD: g.opt_fold = value ? 1 : 0; return 0;
     case SVR_OPT_PARK_MIN:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_MIN: bad value %d (1..64)", value);
         g.opt_park_min = value; return 0;
@@ -1045,6 +1093,7 @@ int svr_get_option(int key)
     case SVR_OPT_EMPTY_SKIP: return g.opt_empty_skip;
     case SVR_OPT_RAY_SKIP: return g.opt_ray_skip;
     case SVR_OPT_BOUND_CULL: return g.opt_bound_cull;
+    case SVR_OPT_FOLD: return g.opt_fold;
     case SVR_OPT_PARK_MIN: return g.opt_park_min;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     case SVR_OPT_FRAMES_PER_WAVE_LOG2: return g.opt_frames_log2;

@@ -92,6 +92,8 @@ struct DevWork {
     uint32_t n_items;              // owned pixels = n_rows * (x1-x0)
     uint32_t unit;                 // tile kernel: consecutive tasks handed out per ticket
     uint32_t frames_log2;          // tile kernel: log2(frames per wave); a wave = (64 >> f) pixels x (1 << f) frames
+    uint32_t fold;                 // tile kernel: 1 = fold the group's frames into hdr in the kernel (running mean in frame order;
+                                   // needs nframes <= 64 so that a pixel's frames sit in one wave); 0 = write the scratch slots
     uint32_t debug_stop;           // timing ablation only (0 = off): 1 stop after set-up, 2 after the whole-ray test, 3 after the primary walk
     uint32_t refill_min_idle;      // persistent kernel: regenerate lanes once this many are idle (64 = tile-synchronous)
     unsigned long long* counters;  // svr_counters on the device, or null

@@ -24,6 +24,13 @@
 
 namespace svr {
 
+// timing-ablation stops (DevWork.debug_stop, wrong images) exist only in experiment builds
+#ifdef SVR_TEST_HOOKS
+#define SVR_DEBUG_STOPS 1
+#else
+#define SVR_DEBUG_STOPS 0
+#endif
+
 // wave-synchronous re-marching of walks that leave an occupied stretch (svr_walk.hpp, REMARCH).  Measured on c3
 // (ms per frame): none 0.323, shadow walks only 0.292, primary only 0.400, both 0.376 -- shadow walks start inside
 // the medium and almost always end at the march; a primary march is paid by every tile that has one grazing ray.
@@ -40,7 +47,7 @@ namespace svr {
 // the next-event estimate, which leaves registers for the re-marching shadow walk.
 template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS>
 SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_t y, uint32_t traceDepth_,
-                           uint32_t hashed, uint32_t debug_stop, bool group_march, uint32_t P2, Cnt& c)
+                           uint32_t hashed, uint32_t debug_stop, bool group_march, uint32_t P2, GroupMapShared* gslot, Cnt& c)
 {
     const uint32_t traceDepth = DEPTH1 ? 1u : traceDepth_;
     uint32_t offset = y * s.imageW + x;
@@ -52,8 +59,8 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
     camera_ray(s, x, y, rng, orig, dir);
     float ls_t;
     int ls_id = nearest_light(s, orig, dir, ls_t);
-    if (debug_stop == 1u) return V3(ls_t, orig.x, dir.x);
-    if (debug_stop == 2u) {
+    if (SVR_DEBUG_STOPS && debug_stop == 1u) return V3(ls_t, orig.x, dir.x);
+    if (SVR_DEBUG_STOPS && debug_stop == 2u) {
         float tn, tf;
         if (!volume_intersect(s, orig, dir, tn, tf)) return V3(0.f, 0.f, 0.f);
         return V3(first_occupied(s, L_, orig, dir, tn < 0.f ? 1e-6f : tn, tf), 0.f, 0.f);
@@ -65,12 +72,13 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
             // the wave is full and its lanes are pixels x frames: one shared whole-ray test per pixel
             float t_occ;
             GroupMap map;
+            map.g = gslot + ((threadIdx.x & 63u) & ((1u << P2) - 1u) & (GROUP_MAPS_PER_WAVE - 1u));      // this wave's slot of the lane's pixel group
             int r = walk_setup_group<COUNT, SKIP>(s, L_, P2, orig, dir, false, tMin, tMax, t_occ, map);
             t = r <= 0 ? -SVR_FLT_MAX
                        : walk_run<LAYOUT, COUNT, SKIP, false, true>(s, L_, orig, dir, rng, tMin, tMax, t_occ, val, false, c, &map, P2);
         } else
             t = walk<LAYOUT, COUNT, SKIP, SVR_PRIMARY_REMARCH>(s, L_, orig, dir, rng, tMin, tMax, val, false, c);
-        if (debug_stop == 3u) return V3(t, val, 0.f);
+        if (SVR_DEBUG_STOPS && debug_stop == 3u) return V3(t, val, 0.f);
         if (k == 0 && ls_id >= 0) {
             t = t < 0.f ? SVR_FLT_MAX : t;
             if (ls_t < t) {
@@ -113,7 +121,7 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
             if (sample_light(s.lights[lightId], vs.pt, rng, wiL, pdfL, Li)) {
                 float sMin = (float)1e-6, sMax = SVR_FLT_MAX, sval = 0.f;
                 if (COUNT) c.shadow++;
-                if (debug_stop == 4u) return V3(wiL.x, pdfL, Li.x + vs.Pbrdf);
+                if (SVR_DEBUG_STOPS && debug_stop == 4u) return V3(wiL.x, pdfL, Li.x + vs.Pbrdf);
                 // the draws of sample_bsdf / roulette follow the shadow walk unless this is the last bounce
                 float ts = walk<LAYOUT, COUNT, SKIP, SVR_SHADOW_REMARCH>(s, L_, vs.pt, wiL, rng, sMin, sMax, sval, k + 1u < traceDepth, c);
                 float Tr = ((ts > sMin) && (ts < sMax)) ? 0.f : 1.f;          // transmittance.h:15-16
@@ -146,25 +154,93 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
 #define SVR_TILE_THREADS 1024     // 16 waves share one 84 KB LDS image (alpha LUT, two 32 KB bitmasks, 16 KB distance field): one block per CU
 #endif
 
+// Radiance of the last PEND_TASKS tasks of a wave, in LDS, when the launch folds the frames of a pixel into the
+// accumulator itself (DevWork.fold): [task][channel][lane], rows padded to 65 words so that the fold lanes (one per
+// pixel and channel) read conflict-free.
+constexpr uint32_t PEND_TASKS = 4;
+constexpr uint32_t PEND_ROW = 65;
+constexpr uint32_t TILE_WAVES = SVR_TILE_THREADS / 64;
+struct LdsPend {
+    float L[TILE_WAVES][PEND_TASKS * 3][PEND_ROW];
+    uint32_t task[TILE_WAVES][PEND_TASKS];
+};
+
+// task index of the centre-out order -> tile row, tile column, frame group (see the kernel)
+struct TaskShape { uint32_t tiles_x, tiles_y, fgroups, row_tasks, c_row, tw2, th2, P2, fl2, wv; };
+SVR_DEV TaskShape task_shape(const DevWork& w)
+{
+    TaskShape ts;
+    ts.wv = w.x1 - w.x0;
+    ts.fl2 = w.frames_log2;                                   // 0..6
+    ts.P2 = 6u - ts.fl2;                                      // log2(pixels per wave)
+    ts.tw2 = (ts.P2 + 1u) >> 1; ts.th2 = ts.P2 >> 1;          // pixel block 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
+    ts.tiles_x = (ts.wv + (1u << ts.tw2) - 1u) >> ts.tw2;
+    ts.tiles_y = (w.n_rows + (1u << ts.th2) - 1u) >> ts.th2;
+    ts.fgroups = (w.nframes + (1u << ts.fl2) - 1u) >> ts.fl2;
+    ts.row_tasks = ts.tiles_x * ts.fgroups;                   // tasks of one tile row
+    ts.c_row = ts.tiles_y >> 1;
+    return ts;
+}
+SVR_DEV void task_decode(const TaskShape& ts, uint32_t k, uint32_t& tx, uint32_t& ty, uint32_t& fg)
+{
+    const uint32_t rr = k / ts.row_tasks, in_row = k - rr * ts.row_tasks;
+    const uint32_t off = (rr + 1u) >> 1;
+    ty = (rr & 1u) ? ts.c_row - off : ts.c_row + off;
+    tx = in_row / ts.fgroups;
+    fg = in_row - tx * ts.fgroups;
+}
+
+// running_estimate (pathtracer.cu:81-84,279) for the pending tasks of this wave: the 1 << fl2 lanes of a task that
+// hold one pixel are that pixel's frames frame0 .. frame0 + nframes - 1 IN ORDER, so one lane per (pixel, channel)
+// replays the reference's sequence acc += (L - acc) / (n + 1) frame by frame -- the same float operations in the same
+// order as nframes calls of the reference -- and the accumulator is read and written once per launch (12 B per
+// pixel) instead of once per frame.  clear_hdr_buffer (pathtracer.cu:86-94) is the frame0 == 0 case.
+SVR_DEV void fold_pending(const DevScene& s, const DevWork& w, LdsPend& P, uint32_t wave, uint32_t npend)
+{
+    const TaskShape ts = task_shape(w);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t npx = 1u << ts.P2;
+    const uint32_t items = npend * npx * 3u;
+    const uint32_t nfr = min(w.nframes, 1u << ts.fl2);
+    for (uint32_t i = lane; i < items; i += 64u) {
+        const uint32_t pi = (i * 0xAAABu) >> 17;           // i / 3 for i < 2^15
+        const uint32_t ch = i - 3u * pi;
+        const uint32_t q = pi >> ts.P2, pl = pi & (npx - 1u);
+        uint32_t tx, ty, fg;
+        task_decode(ts, P.task[wave][q], tx, ty, fg);
+        const uint32_t px = (tx << ts.tw2) + (pl & ((1u << ts.tw2) - 1u));
+        const uint32_t r = (ty << ts.th2) + (pl >> ts.tw2);
+        if (px >= ts.wv || r >= w.n_rows) continue;
+        const uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
+        float* h = w.hdr + 3 * ((size_t)y * s.imageW + x) + ch;
+        float acc = (w.frame0 == 0u) ? 0.f : *h;
+        const float* row = &P.L[wave][q * 3u + ch][pl];
+        for (uint32_t f = 0; f < nfr; ++f) {
+            const float Lf = row[f << ts.P2];
+            const float n1 = (float)(w.frame0 + f) + 1.f;
+            acc = acc + (Lf - acc) / n1;
+        }
+        *h = acc;
+    }
+}
+
 template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1>
 __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_trace_tile(const DevScene s, const DevWork w)
 {
     using LDS = typename std::conditional<SKIP, LdsTileCull, LdsTileNoMask>::type;
     __shared__ LDS lds;
+    __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
+    __shared__ LdsPend pend;
     lds_tile_load(lds, s, SKIP);
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = w.x1 - w.x0;
+    const uint32_t wave = threadIdx.x >> 6;
     // Lanes of a wave = (64 >> fl2) pixels x (1 << fl2) frames of the group: rays of one pixel in different frames
     // share origin, box segment and whole-ray test result up to sub-pixel jitter, so a wave is far more uniform
     // (skip / walk / hit, walk lengths) than 64 different pixels of one frame, and it touches fewer bricks.
-    const uint32_t fl2 = w.frames_log2;                       // 0..6
-    const uint32_t P2 = 6u - fl2;                             // log2(pixels per wave)
-    const uint32_t tw2 = (P2 + 1u) >> 1, th2 = P2 >> 1;       // pixel block 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
-    const uint32_t tiles_x = (wv + (1u << tw2) - 1u) >> tw2;
-    const uint32_t tiles_y = (w.n_rows + (1u << th2) - 1u) >> th2;
-    const uint32_t fgroups = (w.nframes + (1u << fl2) - 1u) >> fl2;
-    const uint32_t n_tasks = tiles_x * tiles_y * fgroups;
+    const TaskShape ts = task_shape(w);
+    const uint32_t fl2 = ts.fl2, P2 = ts.P2, tw2 = ts.tw2, th2 = ts.th2, wv = ts.wv, fgroups = ts.fgroups;
+    const uint32_t n_tasks = ts.tiles_x * ts.tiles_y * fgroups;
     Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // Work distribution.  A single returning atomic saturates near 88 dequeues/us chip-wide
@@ -178,8 +254,8 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
     const uint32_t unit = w.unit;
     const uint32_t n_units = (n_tasks + unit - 1u) / unit;
     const uint32_t shard0 = blockIdx.x % TICKET_SHARDS;
-    const uint32_t row_tasks = tiles_x * fgroups;                 // tasks of one tile row
-    const uint32_t c_row = tiles_y >> 1;
+    const bool fold = w.fold != 0u;                               // host guarantees fgroups == 1 then
+    uint32_t npend = 0;
 
     for (uint32_t si = 0; si < TICKET_SHARDS; ++si) {
         const uint32_t shard = (shard0 + si) % TICKET_SHARDS;
@@ -198,27 +274,36 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
             const uint32_t t_end = min(t_begin + unit, n_tasks);
             for (uint32_t k = t_begin; k < t_end; ++k) {
                 // k-th task of the centre-out order -> (tile row, tile column, frame group)
-                const uint32_t rr = k / row_tasks, in_row = k - rr * row_tasks;
-                const uint32_t off = (rr + 1u) >> 1;
-                const uint32_t ty = (rr & 1u) ? c_row - off : c_row + off;
+                uint32_t tx, ty, fg;
+                task_decode(ts, k, tx, ty, fg);
                 if (COUNT) c.loops += (lane == 0);
-                const uint32_t tx = in_row / fgroups, fg = in_row - tx * fgroups;
                 uint32_t pl = lane & ((1u << P2) - 1u);
                 uint32_t slot = (fg << fl2) + (lane >> P2);
                 uint32_t px = (tx << tw2) + (pl & ((1u << tw2) - 1u));
                 uint32_t r = (ty << th2) + (pl >> tw2);
                 const bool live = px < wv && r < w.n_rows && slot < w.nframes;
                 // shared whole-ray test: >= 8 frames of a pixel in the wave, every lane alive (the group shuffles)
-                const bool group_march = SKIP && fl2 >= 3u && (w.debug_stop == 0u || w.debug_stop >= 3u) && __ballot(live) == ~0ull;
+                const bool group_march = SKIP && fl2 >= 3u && (!SVR_DEBUG_STOPS || w.debug_stop == 0u || w.debug_stop >= 3u) && __ballot(live) == ~0ull;
+                v3 L = V3(0.f, 0.f, 0.f);
                 if (live) {
                     uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
-                    v3 L = trace_path_tile<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, x, y, w.traceDepth, wang_hash(w.frame0 + slot), w.debug_stop, group_march, P2, c);
-                    float* o = w.lbuf + (size_t)slot * w.slot_stride + 3 * ((size_t)y * s.imageW + x);
-                    o[0] = L.x; o[1] = L.y; o[2] = L.z;
+                    L = trace_path_tile<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, x, y, w.traceDepth, wang_hash(w.frame0 + slot), w.debug_stop, group_march, P2,
+                                                                     &gmaps[wave][0], c);
+                    if (!fold) {
+                        float* o = w.lbuf + (size_t)slot * w.slot_stride + 3 * ((size_t)y * s.imageW + x);
+                        o[0] = L.x; o[1] = L.y; o[2] = L.z;
+                    }
+                }
+                if (fold) {
+                    float* pl_row = &pend.L[wave][npend * 3u][lane];
+                    pl_row[0] = L.x; pl_row[PEND_ROW] = L.y; pl_row[2u * PEND_ROW] = L.z;
+                    if (lane == 0) pend.task[wave][npend] = k;
+                    if (++npend == PEND_TASKS) { fold_pending(s, w, pend, wave, npend); npend = 0; }
                 }
             }
         }
     }
+    if (fold && npend) fold_pending(s, w, pend, wave, npend);
     if (COUNT) cnt_flush(w, c);
 }
 
@@ -231,6 +316,12 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
     uint32_t fl2 = 0;
     while (fl2 < 6u && (2u << fl2) <= w.nframes) ++fl2;
     if (cfg.frames_log2 >= 0 && (uint32_t)cfg.frames_log2 < fl2) fl2 = (uint32_t)cfg.frames_log2;
+    if (w.fold) {
+        // in-kernel accumulation: every frame of a pixel must sit in ONE wave (frame lanes 0 .. nframes-1 of its group)
+        if (w.nframes > 64u) return hipErrorInvalidValue;
+        fl2 = 0;
+        while ((1u << fl2) < w.nframes) ++fl2;
+    }
     const uint32_t P2 = 6u - fl2, tw2 = (P2 + 1u) >> 1, th2 = P2 >> 1;
     const uint32_t fgroups = (w.nframes + (1u << fl2) - 1u) >> fl2;
     uint32_t n_tasks = ((wv + (1u << tw2) - 1u) >> tw2) * ((w.n_rows + (1u << th2) - 1u) >> th2) * fgroups;

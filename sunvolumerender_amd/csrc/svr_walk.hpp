@@ -235,16 +235,22 @@ SVR_DEV float first_occupied(const DevScene& s, const LDS& L, v3 o, v3 d, float 
 // segment, a lane can later ask in O(1) where the next possibly-occupied stretch after its current position starts
 // (group_map_next) -- the cheap stand-in for re-marching a primary walk that has come out of an occupied stretch.
 constexpr uint32_t GROUP_MAP_ROUNDS = 3;
+constexpr uint32_t GROUP_MAPS_PER_WAVE = 8;     // a shared march needs >= 8 frames of a pixel in the wave: at most 8 pixel groups
+// One map per PIXEL GROUP, in LDS (every lane of the group computes the same values and stores them to the group's
+// slot; a lane reads back what it -- or a lane with identical data -- wrote, so no ordering between lanes is needed).
+struct GroupMapShared {
+    uint64_t w[GROUP_MAP_ROUNDS];      // round r: bit (j << P2) = sample r * Lg + j is not deep-empty
+    uint64_t pad;
+};
 struct GroupMap {
-    float lo, dt, inv_dt;
-    uint64_t w[GROUP_MAP_ROUNDS];      // round r: bit (j << P2) = sample r * Lg + j is not deep-empty.  Indexed by the round
-                                       // counter, so the compiler keeps the map in LDS (48 B per thread) -- measured
-                                       // faster than three scalars in registers (0.131 vs 0.135 ms per frame: spills)
+    GroupMapShared* g;                 // the group's slot (the sample bits: indexed by the round counter, so they live in memory)
+    float lo, dt, inv_dt;              // sample k sits at lo + k * dt (per-lane copies: registers)
     bool valid;                        // the map covers the whole segment and this lane may use it
 };
 
-SVR_DEV float group_map_next(const GroupMap& g, uint32_t P2, float t)
+SVR_DEV float group_map_next(const GroupMap& gm, uint32_t P2, float t)
 {
+    struct { float lo, dt, inv_dt; const uint64_t* w; } g = {gm.lo, gm.dt, gm.inv_dt, gm.g->w};
     const uint32_t fl2 = 6u - P2, Lg = 64u >> P2;
     // a sample at or before t (one earlier than the quotient says, against rounding): coverage from t_k includes t
     int ki = (int)((t - g.lo) * g.inv_dt) - 1;
@@ -264,8 +270,9 @@ template <typename LDS>
 SVR_DEV float first_occupied_group(const DevScene& s, const LDS& L, uint32_t P2, v3 o, v3 d, bool hit, float tMin, float tMax, bool& ok,
                                    GroupMap& map)
 {
+    GroupMapShared& ms = *map.g;
     map.valid = false; map.lo = 0.f; map.dt = 1.f; map.inv_dt = 1.f;
-    for (uint32_t r = 0; r < GROUP_MAP_ROUNDS; ++r) map.w[r] = 0ull;
+    for (uint32_t r = 0; r < GROUP_MAP_ROUNDS; ++r) ms.w[r] = 0ull;
     const float INF = u2f(SVR_INF_BITS);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t pl = lane & ((1u << P2) - 1u), m = lane >> P2, Lg = 64u >> P2;
@@ -303,7 +310,7 @@ SVR_DEV float first_occupied_group(const DevScene& s, const LDS& L, uint32_t P2,
         const uint32_t q = (uint32_t)(ix + iy * gx + iz * s.mc_gxy);
         const bool occupied = (tk <= hi) && !((L.mask[q >> 5] >> (q & 31u)) & 1u);
         const uint64_t b = __ballot(occupied) & gmask;
-        if (round < GROUP_MAP_ROUNDS) map.w[round] = b >> pl;
+        if (round < GROUP_MAP_ROUNDS) ms.w[round] = b >> pl;
         if (b && !found) { found = true; result = fma_((float)(k0 + (((uint32_t)__builtin_ctzll(b) - pl) >> P2)), dt, lo); }
         const bool at_end = fma_((float)(k0 + Lg - 1u), dt, lo) > hi;      // the round reached the end of the segment
         if (at_end) { complete = round < GROUP_MAP_ROUNDS; break; }
@@ -360,6 +367,96 @@ SVR_DEV int walk_setup_group(const DevScene& s, const LDS& L, uint32_t P2, v3 or
     return hit ? 1 : -1;
 }
 
+// REMARCH: a walk that comes out of an occupied stretch into clear space (two consecutive iterations in
+// deep-empty cells) PARKS: it leaves the iteration loop.  The lanes of a wave reconverge at the loop exit, so the
+// parked lanes march again TOGETHER (a per-lane march inside the loop is serialised by divergence and was
+// slower than not marching at all).  If nothing occupied lies ahead and no draw follows the walk, its result
+// (-FLT_MAX) is known; otherwise it resumes with the new t_occ.  COUNT builds keep iterating instead so that
+// the iteration/tap counters stay the reference's.
+// MAP: the walk belongs to a pixel group with a GroupMap (primary walks of frame-major launches): an iteration that
+// lands in an empty cell asks the map for the next possibly-occupied stretch and, if that lies ahead, goes back to
+// fetch-free iterations until then (or ends, if nothing lies ahead and no draw follows the walk).
+template <int LAYOUT, bool COUNT, bool SKIP, bool REMARCH, bool MAP, typename LDS>
+SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float tMin, float tMax, float t_occ,
+                       float& val, bool rng_live, Cnt& c, const GroupMap* map = nullptr, uint32_t P2 = 0u)
+{
+    float t = tMin;
+    const bool ray_skippable = SKIP && s.ray_skip && !rng_live && t_occ == u2f(SVR_INF_BITS);
+    if (COUNT && ray_skippable) c.wskip++;
+    bool tail_counted = false;          // COUNT builds only: a non-counting build would have ended the walk
+    uint32_t guard = 0;
+    for (;;) {
+        // ---- prefix: iterations before the first possibly-occupied macro-cell.  No fetch, sigma_t = 0: each is a
+        //      distance draw + log, the exit test, and the state update of the accept draw (its value is unused) ----
+        bool pending = false;           // t has been advanced and still needs its tap and accept draw
+        if (SKIP) {
+            for (;;) {
+                if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; else c.ipre++; }
+                t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+                if (t > tMax || guard++ >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
+                if (COUNT) c.taps++;
+                if (t >= t_occ) { pending = true; if (COUNT) { c.ipre -= !(ray_skippable || tail_counted); } break; }
+                rng_skip(rng);
+            }
+        }
+        // ---- general iterations (loop rotated: tap first, then advance) ----
+        uint32_t clear_run = 0;
+        for (;;) {
+            if (!pending) {
+                if (COUNT) { c.iters++; if (tail_counted) c.iskip++; }
+                t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+                if (t > tMax || guard++ >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
+                if (COUNT) c.taps++;
+            }
+            pending = false;
+            float sigma_t = 0.f;
+            bool park_now = false;
+            // the accept draw does not depend on the fetch: draw it first (same position in the stream), so that a fetch
+            // the draw rules out (majorant-bound culling, svr_accel.hip) is never issued
+            const float xi = rng_uniform(rng);
+            if (!MAP || t >= t_occ) {
+                v3 p = orig + dir * t;
+                Cell cell = cell_of(s, p);
+                CellInfo ci;
+                ci.empty = false; ci.deep = false; ci.thr = u2f(SVR_INF_BITS);
+                if (SKIP) ci = cell_info<REMARCH && !MAP>(L, s, cell);
+                if (!ci.empty) {
+                    clear_run = 0;
+                    if (xi < ci.thr) {
+                        if (COUNT) c.exec++;
+                        val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
+                        sigma_t = alpha_of(L, s, val);
+                    } else if (COUNT) c.cull++;
+                } else if (SKIP && MAP) {
+                    if (map->valid) {
+                        t_occ = group_map_next(*map, P2, t);          // <= t while the walk is in or next to an occupied stretch
+                        if (t_occ == u2f(SVR_INF_BITS) && !rng_live) {
+                            if (!COUNT) {
+                                // consume nothing further: the walk cannot collide any more and no draw follows it
+                                return -SVR_FLT_MAX;
+                            }
+                            if (!tail_counted) { tail_counted = true; c.wskip++; }
+                        }
+                    }
+                } else if (SKIP && REMARCH) {
+                    // park after two consecutive iterations in DEEP-empty cells (where a march can start)
+                    clear_run = ci.deep ? clear_run + 1u : 0u;
+                    park_now = clear_run == 2u;
+                }
+            }
+            // the accept draw is consumed either way; with sigma_t == 0 it cannot accept (xi > 0)
+            if (xi < sigma_t * s.invSigmaMax) return t;
+            if (park_now) break;
+        }
+        // ---- parked lanes of the wave march together ----
+        t_occ = first_occupied(s, L, orig, dir, t, tMax);
+        if (t_occ == u2f(SVR_INF_BITS) && !rng_live) {
+            if (!COUNT) return -SVR_FLT_MAX;
+            if (!tail_counted) { tail_counted = true; c.wskip++; }
+        }
+    }
+}
+
 // The walk loop.  Every iteration of the reference (woodcock_tracking.h:32-45) is: distance draw + log + advance, the
 // exit test, one fetch, the accept draw + test.  Here a lane's iteration is one of
 //   * FREE    t < t_occ (before the first possibly-occupied macro-cell, whole-ray march): no cell test, no fetch;
@@ -377,8 +474,8 @@ SVR_DEV int walk_setup_group(const DevScene& s, const LDS& L, uint32_t P2, v3 or
 // MAP: the walk belongs to a pixel group with a GroupMap (primary walks of frame-major launches): an iteration in
 // an empty cell asks the map for the next possibly-occupied stretch and goes back to FREE iterations until then.
 template <int LAYOUT, bool COUNT, bool SKIP, bool REMARCH, bool MAP, typename LDS>
-SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float tMin, float tMax, float t_occ,
-                       float& val, bool rng_live, Cnt& c, const GroupMap* map = nullptr, uint32_t P2 = 0u)
+SVR_DEV float walk_run_parked(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float tMin, float tMax, float t_occ,
+                              float& val, bool rng_live, Cnt& c, const GroupMap* map = nullptr, uint32_t P2 = 0u)
 {
     enum : uint32_t { RUN = 0u, NEED_FETCH = 1u, NEED_MARCH = 2u, DONE = 3u };
     const float INF = u2f(SVR_INF_BITS);
