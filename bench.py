@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--extra-steps", type=int, default=2)
     ap.add_argument("--empty-skip", type=int, default=1)
     ap.add_argument("--fast-math", type=int, default=0)
+    ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE",
+                    help="library option by name (abi.OPT_<NAME>), e.g. --set queue=0 --set park_end=8; experiments only")
     return ap.parse_args()
 
 
@@ -281,6 +283,9 @@ def main():
         dev.set_option(abi.OPT_FAST_MATH, 1)
     if args.blocks_per_cu:
         dev.set_option(abi.OPT_BLOCKS_PER_CU, args.blocks_per_cu)
+    for kv in args.set:
+        name, value = kv.split("=")
+        dev.set_option(getattr(abi, "OPT_" + name.upper()), int(value))
     asm = None
     if world > 1:
         dist.shard(dev, args.strip_rows, rank, world)

@@ -18,7 +18,7 @@ LIB_DIR = PKG_DIR / "lib"
 LIB_PATH = Path(os.environ["SVR_HIP_LIB"]) if os.environ.get("SVR_HIP_LIB") else LIB_DIR / "libsvr_hip.so"
 
 HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_wavefront.hip", "svr_accel.hip", "svr_raycast.hip", "svr_host_io.hip", "svr_volume_prep.hip", "svr_selftest.hip"]
-HIP_HEADERS = ["svr_math.hpp", "svr_scene.hpp", "svr_device.hpp", "svr_kernels.hpp", "svr_kernel_common.hpp", "svr_walk.hpp"]
+HIP_HEADERS = ["svr_math.hpp", "svr_scene.hpp", "svr_device.hpp", "svr_kernels.hpp", "svr_kernel_common.hpp", "svr_walk.hpp", "svr_lanes.hpp"]
 
 HIPCC_FLAGS = [
     "-O3",
@@ -57,7 +57,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
     from concurrent.futures import ThreadPoolExecutor
 
     LIB_DIR.mkdir(exist_ok=True)
-    obj_dir = LIB_DIR / "obj"
+    obj_dir = LIB_DIR / ("obj" if LIB_PATH.name == "libsvr_hip.so" else "obj_" + LIB_PATH.stem)   # variant builds (SVR_HIP_LIB) keep their own objects
     obj_dir.mkdir(exist_ok=True)
     common = [CSRC / f for f in HIP_HEADERS] + [REPO_ROOT / "include" / "svr_abi.h", REPO_ROOT / "include" / "svr_io.h",
                                                 CSRC / "svr_internal.hpp", Path(__file__)]

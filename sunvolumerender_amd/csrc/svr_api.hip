@@ -36,6 +36,7 @@ static_assert(sizeof(svr_counters) == 8 * svr::CNT_N, "counter block");
 namespace {
 
 enum TexKind { TEX_VOLUME = 1, TEX_TF = 2, TEX_ENV = 3 };
+constexpr size_t DEBUG_WORDS = 32;
 
 struct Texture {
     uint32_t magic;
@@ -76,6 +77,9 @@ struct Context {
     // device scratch
     unsigned long long* d_counters = nullptr;
     uint32_t* d_ticket = nullptr;
+    uint32_t* d_queue = nullptr;        // scatter-record queues of the tile kernel's folding launches (they run one at a time)
+    float* d_pend = nullptr;            // ... and the waves' pending-radiance rows
+    uint32_t queue_blocks = 0;          // blocks both are sized for
     hipEvent_t prev_traced = nullptr;   // `traced` event of the latest trace launch (owned by its set)
     // frames traced ahead of the host's render_pathtracer calls (render_frames)
     struct Ahead {
@@ -109,7 +113,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 16, opt_fold = 1;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 1, opt_park_end = 16, opt_fold = 1, opt_queue = 1;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint8_t* d_mask_tmp = nullptr;     // scratch of the distance transform
@@ -190,8 +194,8 @@ int ensure_init()
     char buf[256];
     snprintf(buf, sizeof buf, "%s %d.%d %s CUs=%d", prop.name, prop.major, prop.minor, prop.gcnArchName, g.num_cus);
     g.info = buf;
-    HIP_TRY(hipMalloc((void**)&g.d_counters, sizeof(svr_counters)));
-    HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
+    HIP_TRY(hipMalloc((void**)&g.d_counters, sizeof(svr_counters) + DEBUG_WORDS * 8));       // + the phase profile of experiment builds
+    HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters) + DEBUG_WORDS * 8));
     HIP_TRY(hipMalloc((void**)&g.d_ticket, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * (Context::NSETS + 1)));
     HIP_TRY(hipMemset(g.d_ticket, 0, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * (Context::NSETS + 1)));
     HIP_TRY(hipMalloc((void**)&g.d_mask, svr::ACCEL_WORDS * sizeof(uint32_t)));
@@ -448,6 +452,7 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
     s.ray_skip = (inside && g.opt_ray_skip) ? 1u : 0u;
     s.bound_cull = (g.opt_bound_cull == 2 || (g.opt_bound_cull == 1 && g.mask_cull_useful)) ? 1u : 0u;
     s.park_min = (uint32_t)g.opt_park_min;
+    s.park_end = (uint32_t)g.opt_park_end;
     return 0;
 }
 
@@ -466,6 +471,23 @@ int ensure_slots(uint32_t W, uint32_t H, uint32_t nslots)
     if (g.slot_floats != need || nslots > g.slots_per_set) g.slots_per_set = nslots;
     for (auto& st : g.sets) HIP_TRY(hipMalloc((void**)&st.lbuf, need * sizeof(float) * g.slots_per_set));
     g.slot_floats = need;
+    return 0;
+}
+
+// per-wave scatter-record queues (REC_WORDS x QUEUE_CAP words) and pending-radiance rows (QUEUE_TASKS x 3 x 64 floats) of the
+// tile kernel's QUEUE builds (svr_trace_tile.hip, svr_lanes.hpp): 57 KB + 24 KB per wave, 330 MB for 256 blocks
+constexpr size_t QUEUE_WORDS_PER_BLOCK = (size_t)14 * 1024 * 16;
+constexpr size_t PEND_FLOATS_PER_BLOCK = (size_t)32 * 3 * 64 * 16;
+int ensure_record_queues(uint32_t blocks)
+{
+    if (g.d_queue && g.queue_blocks >= blocks) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    if (g.d_queue) { HIP_TRY(hipFree(g.d_queue)); g.d_queue = nullptr; }
+    if (g.d_pend) { HIP_TRY(hipFree(g.d_pend)); g.d_pend = nullptr; }
+    g.queue_blocks = 0;
+    HIP_TRY(hipMalloc((void**)&g.d_queue, QUEUE_WORDS_PER_BLOCK * sizeof(uint32_t) * blocks));
+    HIP_TRY(hipMalloc((void**)&g.d_pend, PEND_FLOATS_PER_BLOCK * sizeof(float) * blocks));
+    g.queue_blocks = blocks;
     return 0;
 }
 
@@ -518,6 +540,11 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     // pixel per launch, svr_trace_tile.hip); the scratch slots + k_resolve remain for frames traced AHEAD of the calls
     // that ask for them (their radiance is folded later, one frame per call) and for the other kernels.
     const bool fold_batch = cfg.kernel == svr::KERNEL_TILE && g.opt_fold && !g.opt_debug_stop && cfg.frames_log2 < 0;
+    // QUEUE builds (paths continue on a per-lane state machine after their first scatter event, svr_lanes.hpp) pay where what
+    // follows the first event is long and incoherent: deeper paths, and media that cannot be skipped (auto: the scenes
+    // where bound culling applies); they ride on the folding launches
+    const bool use_queue = fold_batch && (g.opt_queue == 2 || (g.opt_queue == 1 && (rp->traceDepth > 1 || s.bound_cull)));
+    if (use_queue && ensure_record_queues((uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / 16u)) return g.err_code;
     const bool frame_ahead_call = nframes == 1 && g.opt_frame_ahead && g.opt_pipeline && !g.opt_count && !g.opt_debug_stop && cfg.kernel == svr::KERNEL_TILE;
     // short launches (< FOLD_MIN frames) keep the slots: they end in a tail of a few long tasks that only overlapping launches
     // on several streams hide, and a folding launch cannot overlap its predecessor (measured, 1 frame per call: 0.276 vs 0.366 ms)
@@ -537,6 +564,9 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         w.frame0 = first;
         w.nframes = n;
         w.fold = 1u;
+        w.queue = use_queue ? g.d_queue : nullptr;
+        w.pend = use_queue ? g.d_pend : nullptr;
+        w.queue_blocks = g.queue_blocks;
         int slot = -1;
         if (g.opt_timing) {
             if (g.ev_count == Context::EV_RING) collect_timing();
@@ -716,6 +746,8 @@ void svr_shutdown(void)
     if (g.d_mask_tmp) hipFree(g.d_mask_tmp);
     if (g.d_counters) hipFree(g.d_counters);
     if (g.d_ticket) hipFree(g.d_ticket);
+    if (g.d_queue) hipFree(g.d_queue);
+    if (g.d_pend) hipFree(g.d_pend);
     for (int i = 0; i < Context::EV_RING; ++i) {
         if (g.ev0[i]) hipEventDestroy(g.ev0[i]);
         if (g.ev1[i]) hipEventDestroy(g.ev1[i]);
@@ -1058,6 +1090,12 @@ int svr_set_option(int key, int value)
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_BOUND_CULL: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_bound_cull = value; return 0;
     case SVR_OPT_FOLD: g.opt_fold = value ? 1 : 0; return 0;
+    case SVR_OPT_QUEUE:
+        if (value < 0 || value > 2) return fail(-6, "SVR_OPT_QUEUE: bad value %d (0 off, 1 auto, 2 always)", value);
+        g.opt_queue = value; return 0;
+    case SVR_OPT_PARK_END:
+        if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_END: bad value %d (1..64)", value);
+        g.opt_park_end = value; return 0;
     case SVR_OPT_PARK_MIN:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_MIN: bad value %d (1..64)", value);
         g.opt_park_min = value; return 0;
@@ -1094,6 +1132,8 @@ int svr_get_option(int key)
     case SVR_OPT_RAY_SKIP: return g.opt_ray_skip;
     case SVR_OPT_BOUND_CULL: return g.opt_bound_cull;
     case SVR_OPT_FOLD: return g.opt_fold;
+    case SVR_OPT_QUEUE: return g.opt_queue;
+    case SVR_OPT_PARK_END: return g.opt_park_end;
     case SVR_OPT_PARK_MIN: return g.opt_park_min;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     case SVR_OPT_FRAMES_PER_WAVE_LOG2: return g.opt_frames_log2;
@@ -1137,6 +1177,17 @@ int svr_selftest_math(int fn, const float* in, uint32_t in_stride, float* out, u
     return 0;
 }
 
+#ifdef SVR_TEST_HOOKS
+// experiment builds: the lane machine's phase profile (svr_lanes.hpp), n <= 32 words, cleared by svr_reset_counters
+extern "C" int svr_debug_phase_profile(uint64_t* out, int n)
+{
+    if (ensure_init()) return g.err_code;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, g.d_counters + svr::CNT_N, sizeof(uint64_t) * (size_t)(n < (int)DEBUG_WORDS ? n : (int)DEBUG_WORDS), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
 int svr_get_counters(svr_counters* out)
 {
     if (ensure_init()) return g.err_code;
@@ -1150,7 +1201,7 @@ int svr_reset_counters(void)
 {
     if (ensure_init()) return g.err_code;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters)));
+    HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters) + DEBUG_WORDS * 8));
     return 0;
 }
 

@@ -47,7 +47,8 @@ struct DevScene {
     uint32_t mask_words, dist_words;
     uint32_t ray_skip;             // 1: the clipped box lies inside the texture domain, so whole-ray tests are valid
     uint32_t bound_cull;           // 1: the bound-class table behind the masks is valid (majorant-bound fetch culling)
-    uint32_t park_min;             // walk loop: lanes waiting for a fetch / a re-march before the wave serves them
+    uint32_t park_min;             // lane machine: lanes waiting for a fetch / a re-march before the wave serves them
+    uint32_t park_end;             // lane machine: lanes waiting for shading / a walk's end / a new record before the wave serves them
     float mc_scale[3];             // macro-grid coordinate = (p - vmin) * mc_scale + mc_off
     float mc_off;
     // ---- cudaTransferFunction ----
@@ -98,6 +99,9 @@ struct DevWork {
     uint32_t refill_min_idle;      // persistent kernel: regenerate lanes once this many are idle (64 = tile-synchronous)
     unsigned long long* counters;  // svr_counters on the device, or null
     uint32_t* ticket;              // persistent kernel work counter
+    uint32_t* queue;               // tile kernel, QUEUE builds: scatter-record queues, REC_WORDS * QUEUE_CAP words per wave; null = straight-line paths
+    float* pend;                   // ... and the waves' pending-radiance rows, QUEUE_TASKS * 3 * 64 floats per wave
+    uint32_t queue_blocks;         // blocks the queue memory is sized for
 };
 
 } // namespace svr

@@ -21,6 +21,7 @@
 //    multiplies.
 // Radiance goes to the scratch slots; k_resolve (svr_kernels.hip) folds it into the running mean.
 #include "svr_walk.hpp"
+#include "svr_lanes.hpp"
 
 namespace svr {
 
@@ -147,6 +148,52 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
     return L;
 }
 
+// The part of a path up to its first scatter event (k = 0 of kernel_pathtracer's loop, pathtracer.cu:205-235) for QUEUE
+// builds: returns true if the primary walk collided -- pt / wo / val / rng are then what a scatter record holds and
+// svr_lanes.hpp continues the path -- and false if the path is over, with its radiance in L.
+template <int LAYOUT, bool COUNT, bool SKIP, typename LDS>
+SVR_DEV bool trace_primary(const DevScene& s, const LDS& L_, uint32_t x, uint32_t y, uint32_t hashed, bool group_march, uint32_t P2,
+                           GroupMapShared* gslot, Cnt& c, Rng& rng, v3& L, v3& pt, v3& wo, float& val)
+{
+    uint32_t offset = y * s.imageW + x;
+    rng_init(rng, hashed + offset);
+    if (COUNT) c.paths++;
+    L = V3(0.f, 0.f, 0.f);
+    const v3 T = V3(1.f, 1.f, 1.f);
+    v3 orig, dir;
+    camera_ray(s, x, y, rng, orig, dir);
+    float ls_t;
+    int ls_id = nearest_light(s, orig, dir, ls_t);
+    float tMin = (float)1e-6, tMax = SVR_FLT_MAX;
+    val = 0.f;
+    float t;
+    if (SKIP && group_march) {
+        float t_occ;
+        GroupMap map;
+        map.g = gslot + ((threadIdx.x & 63u) & ((1u << P2) - 1u) & (GROUP_MAPS_PER_WAVE - 1u));
+        int r = walk_setup_group<COUNT, SKIP>(s, L_, P2, orig, dir, false, tMin, tMax, t_occ, map);
+        t = r <= 0 ? -SVR_FLT_MAX
+                   : walk_run<LAYOUT, COUNT, SKIP, false, true>(s, L_, orig, dir, rng, tMin, tMax, t_occ, val, false, c, &map, P2);
+    } else
+        t = walk<LAYOUT, COUNT, SKIP, SVR_PRIMARY_REMARCH>(s, L_, orig, dir, rng, tMin, tMax, val, false, c);
+    if (ls_id >= 0) {
+        float tt = t < 0.f ? SVR_FLT_MAX : t;
+        if (ls_t < tt) {
+            const DevLight& l = s.lights[ls_id];
+            float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -dir);
+            L = L + (T * V3(l.radiance[0], l.radiance[1], l.radiance[2])) * (cosTerm <= 0.f ? 0.f : 1.f);
+            return false;
+        }
+    }
+    if (t < 0.f) {
+        if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+        return false;
+    }
+    wo = -dir;
+    pt = orig + dir * t;
+    return true;
+}
+
 #ifndef SVR_TILE_WAVES_PER_EU
 #define SVR_TILE_WAVES_PER_EU 4
 #endif
@@ -159,10 +206,17 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
 // pixel and channel) read conflict-free.
 constexpr uint32_t PEND_TASKS = 4;
 constexpr uint32_t PEND_ROW = 65;
+// QUEUE builds keep the radiance of the last QUEUE_TASKS tasks in a per-wave buffer in global memory instead (rows of 64
+// floats; written and read back by the same CU, so it lives in L2), and up to QUEUE_CAP scatter records per wave
+constexpr uint32_t QUEUE_TASKS = 32;
+constexpr uint32_t QUEUE_CAP = 1024;
 constexpr uint32_t TILE_WAVES = SVR_TILE_THREADS / 64;
 struct LdsPend {
     float L[TILE_WAVES][PEND_TASKS * 3][PEND_ROW];
     uint32_t task[TILE_WAVES][PEND_TASKS];
+};
+struct LdsPendQueue {                              // QUEUE builds: only the task numbers stay in LDS
+    uint32_t task[TILE_WAVES][QUEUE_TASKS];
 };
 
 // task index of the centre-out order -> tile row, tile column, frame group (see the kernel)
@@ -195,7 +249,8 @@ SVR_DEV void task_decode(const TaskShape& ts, uint32_t k, uint32_t& tx, uint32_t
 // replays the reference's sequence acc += (L - acc) / (n + 1) frame by frame -- the same float operations in the same
 // order as nframes calls of the reference -- and the accumulator is read and written once per launch (12 B per
 // pixel) instead of once per frame.  clear_hdr_buffer (pathtracer.cu:86-94) is the frame0 == 0 case.
-SVR_DEV void fold_pending(const DevScene& s, const DevWork& w, LdsPend& P, uint32_t wave, uint32_t npend)
+// rows: [task * 3 + channel] rows of `row` floats (this wave's), tasks: their task numbers
+SVR_DEV void fold_pending(const DevScene& s, const DevWork& w, const float* rows, uint32_t row, const uint32_t* tasks, uint32_t npend)
 {
     const TaskShape ts = task_shape(w);
     const uint32_t lane = threadIdx.x & 63u;
@@ -207,16 +262,16 @@ SVR_DEV void fold_pending(const DevScene& s, const DevWork& w, LdsPend& P, uint3
         const uint32_t ch = i - 3u * pi;
         const uint32_t q = pi >> ts.P2, pl = pi & (npx - 1u);
         uint32_t tx, ty, fg;
-        task_decode(ts, P.task[wave][q], tx, ty, fg);
+        task_decode(ts, tasks[q], tx, ty, fg);
         const uint32_t px = (tx << ts.tw2) + (pl & ((1u << ts.tw2) - 1u));
         const uint32_t r = (ty << ts.th2) + (pl >> ts.tw2);
         if (px >= ts.wv || r >= w.n_rows) continue;
         const uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
         float* h = w.hdr + 3 * ((size_t)y * s.imageW + x) + ch;
         float acc = (w.frame0 == 0u) ? 0.f : *h;
-        const float* row = &P.L[wave][q * 3u + ch][pl];
+        const float* rp = rows + (size_t)(q * 3u + ch) * row + pl;
         for (uint32_t f = 0; f < nfr; ++f) {
-            const float Lf = row[f << ts.P2];
+            const float Lf = rp[f << ts.P2];
             const float n1 = (float)(w.frame0 + f) + 1.f;
             acc = acc + (Lf - acc) / n1;
         }
@@ -224,13 +279,13 @@ SVR_DEV void fold_pending(const DevScene& s, const DevWork& w, LdsPend& P, uint3
     }
 }
 
-template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1>
+template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, bool QUEUE>
 __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_trace_tile(const DevScene s, const DevWork w)
 {
     using LDS = typename std::conditional<SKIP, LdsTileCull, LdsTileNoMask>::type;
     __shared__ LDS lds;
     __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
-    __shared__ LdsPend pend;
+    __shared__ typename std::conditional<QUEUE, LdsPendQueue, LdsPend>::type pend;
     lds_tile_load(lds, s, SKIP);
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -255,7 +310,30 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
     const uint32_t n_units = (n_tasks + unit - 1u) / unit;
     const uint32_t shard0 = blockIdx.x % TICKET_SHARDS;
     const bool fold = w.fold != 0u;                               // host guarantees fgroups == 1 then
-    uint32_t npend = 0;
+    uint32_t npend = 0, qcount = 0;
+    LaneQueue Q;
+    Q.cap = QUEUE_CAP;
+    Q.q = QUEUE ? w.queue + (size_t)(blockIdx.x * TILE_WAVES + wave) * (REC_WORDS * QUEUE_CAP) : nullptr;
+    float* const gpend = QUEUE ? w.pend + (size_t)(blockIdx.x * TILE_WAVES + wave) * (QUEUE_TASKS * 3u * 64u) : nullptr;
+    // hand the pending tasks' radiance on.  QUEUE: first drain the scatter records with all 64 lanes (svr_lanes.hpp)
+    auto flush = [&]() {
+        if constexpr (QUEUE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // records and radiance are read back by other lanes of this wave
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, Q, qcount, w.traceDepth, gpend, 64u, c, w.counters + CNT_N);
+            qcount = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#if SVR_PROF
+            unsigned long long* c_prof = w.counters + CNT_N;
+#endif
+            PROF_BEGIN(pfo, PH_FOLD);
+            fold_pending(s, w, gpend, 64u, &pend.task[wave][0], npend);
+            PROF_END(pfo, min(64u, npend * (3u << ts.P2)));
+        } else
+            fold_pending(s, w, &pend.L[wave][0][0], PEND_ROW, &pend.task[wave][0], npend);
+        npend = 0;
+    };
 
     for (uint32_t si = 0; si < TICKET_SHARDS; ++si) {
         const uint32_t shard = (shard0 + si) % TICKET_SHARDS;
@@ -284,6 +362,29 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 const bool live = px < wv && r < w.n_rows && slot < w.nframes;
                 // shared whole-ray test: >= 8 frames of a pixel in the wave, every lane alive (the group shuffles)
                 const bool group_march = SKIP && fl2 >= 3u && (!SVR_DEBUG_STOPS || w.debug_stop == 0u || w.debug_stop >= 3u) && __ballot(live) == ~0ull;
+                if constexpr (QUEUE) {
+                    Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
+                    v3 L = V3(0.f, 0.f, 0.f), pt = L, wo = L;
+                    float val = 0.f;
+                    bool hit = false;
+#if SVR_PROF
+                    unsigned long long* c_prof = w.counters + CNT_N;
+#endif
+                    PROF_BEGIN(pa, PH_PRIMARY);
+                    if (live) {
+                        uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
+                        hit = trace_primary<LAYOUT, COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, pt, wo, val);
+                    }
+                    PROF_END(pa, (uint32_t)__popcll(__ballot(live)));
+                    if (!hit) {
+                        float* o = gpend + (size_t)npend * (3u * 64u) + lane;
+                        o[0] = L.x; o[64] = L.y; o[128] = L.z;
+                    }
+                    queue_push(Q, qcount, hit, pt, wo, val, rng, (npend << 6) | lane);
+                    if (lane == 0) pend.task[wave][npend] = k;
+                    if (++npend == QUEUE_TASKS || qcount + 64u > QUEUE_CAP) flush();
+                    continue;
+                } else {
                 v3 L = V3(0.f, 0.f, 0.f);
                 if (live) {
                     uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
@@ -298,12 +399,13 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                     float* pl_row = &pend.L[wave][npend * 3u][lane];
                     pl_row[0] = L.x; pl_row[PEND_ROW] = L.y; pl_row[2u * PEND_ROW] = L.z;
                     if (lane == 0) pend.task[wave][npend] = k;
-                    if (++npend == PEND_TASKS) { fold_pending(s, w, pend, wave, npend); npend = 0; }
+                    if (++npend == PEND_TASKS) flush();
+                }
                 }
             }
         }
     }
-    if (fold && npend) fold_pending(s, w, pend, wave, npend);
+    if (npend) flush();
     if (COUNT) cnt_flush(w, c);
 }
 
@@ -342,10 +444,23 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
     hipError_t e = hipMemsetAsync(w.ticket, 0, sizeof(uint32_t) * TICKET_SHARDS * TICKET_STRIDE, st);
     if (e != hipSuccess) return e;
     const bool skip = s.empty_mask != nullptr, d1 = w.traceDepth == 1u;
-    if (skip && d1) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, true, true>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2);
-    else if (skip) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, true, false>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2);
-    else if (d1) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, false, true>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2);
-    else hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, false, false>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2);
+    // QUEUE builds need the per-wave record queues (DevWork.queue, sized for `queue_blocks` blocks) and exist for the BRICK layout only
+    const bool queue = LAYOUT == LAYOUT_BRICK && w.fold && w.queue != nullptr && w.pend != nullptr && blocks <= w.queue_blocks;
+#define SVR_LAUNCH_TILE(SK, D1, QU) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, SK, D1, QU>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2)
+    if constexpr (LAYOUT == LAYOUT_BRICK) {
+        if (queue) {
+            if (skip && d1) SVR_LAUNCH_TILE(true, true, true);
+            else if (skip) SVR_LAUNCH_TILE(true, false, true);
+            else if (d1) SVR_LAUNCH_TILE(false, true, true);
+            else SVR_LAUNCH_TILE(false, false, true);
+            return hipGetLastError();
+        }
+    }
+    if (skip && d1) SVR_LAUNCH_TILE(true, true, false);
+    else if (skip) SVR_LAUNCH_TILE(true, false, false);
+    else if (d1) SVR_LAUNCH_TILE(false, true, false);
+    else SVR_LAUNCH_TILE(false, false, false);
+#undef SVR_LAUNCH_TILE
     return hipGetLastError();
 }
 
