@@ -200,11 +200,11 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
                                      majorant-bound fetch culling -- a Woodcock iteration draws its accept number first and
                                      fetches only if it is below (largest alpha reachable in the macro-cell) / sigma_max; bit-identical
                                      results, same random-number stream (csrc/svr_accel.hip, k_bound_class) */
-#define SVR_OPT_PARK_MIN 16         /* lane machine of the tile kernel (csrc/svr_lanes.hpp): lanes that need a fetch or a re-march wait until
-                                     this many lanes of the wave do, then are served together; 1..64, default 1.  Speed only */
-#define SVR_OPT_PARK_END 19         /* ... the same for shading, a walk's end and idle lanes waiting for a record; 1..64, default 16.  Speed only */
+#define SVR_OPT_PARK_MIN 16         /* reserved (experiments with parked fetches, csrc/svr_walk.hpp walk_run_parked); 1..64 */
+#define SVR_OPT_PARK_END 19         /* lane machine of the tile kernel (csrc/svr_lanes.hpp): shading / end-of-walk processing runs when this many
+                                     lanes of the wave wait for it (or none can walk); 1..64, default 24.  Speed only */
 #define SVR_OPT_QUEUE 18            /* the tile kernel queues a path at its first scatter event and continues it on a per-lane state machine that
-                                     keeps the 64 lanes of a wave busy (csrc/svr_lanes.hpp): 0 never, 1 (default) for traceDepth > 1 and for
+                                     keeps the 64 lanes of a wave busy (csrc/svr_lanes.hpp): 0 never, 1 (default) for traceDepth >= 4 and for
                                      media without exactly transparent space, 2 always.  Results identical */
 #define SVR_OPT_FOLD 17             /* 1 (default): a many-frame launch of the tile kernel folds its frames into the HDR accumulator itself (running
                                      mean in frame order, in the wave that traced them); 0: scratch slot per frame + resolve kernel */

@@ -82,7 +82,6 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
     enum : uint32_t { IDLE = 0u, SHADE = 1u, WALK = 2u, FETCH = 3u, MARCH = 4u, END = 5u };
     const float INF = u2f(SVR_INF_BITS);
     const uint32_t traceDepth = DEPTH1 ? 1u : traceDepth_;
-    const uint32_t park_min = s.park_min, park_end = s.park_end;
     uint32_t next = 0u;                       // wave-uniform: next record to pop
     uint32_t st = IDLE;
     // walk state
@@ -109,154 +108,85 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
         st = r > 0 ? WALK : END;
     };
 
+    // one Woodcock iteration of a walking lane without a fetch (woodcock_tracking.h:32-45): FREE / EMPTY / CULLED keep it
+    // in WALK, anything else parks it (FETCH, MARCH) or ends the walk (END)
+    auto iterate = [&]() {
+        if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; }
+        t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+        if (t > tMax || guard++ >= SVR_WALK_GUARD) { st = END; return; }
+        if (COUNT) c.taps++;
+        if (SKIP && t < t_occ) {
+            if (COUNT && !(ray_skippable || tail_counted)) c.ipre++;
+            rng_skip(rng);                                  // the accept draw of a FREE iteration
+            return;
+        }
+        const Cell cell = cell_of(s, orig + dir * t);
+        CellInfo ci;
+        ci.empty = false; ci.deep = false; ci.thr = INF;
+        if (SKIP) ci = cell_info<true>(L_, s, cell);
+        if (ci.empty) {
+            rng_skip(rng);                                  // sigma_t = 0: the draw is consumed, the test fails
+            clear_run = ci.deep ? clear_run + 1u : 0u;
+            if (clear_run == 2u) st = MARCH;
+        } else {
+            clear_run = 0u;
+            xi = rng_uniform(rng);
+            if (xi < ci.thr) st = FETCH;                   // else CULLED: xi >= bound >= sigma_t * invSigmaMax
+            else if (COUNT) c.cull++;
+        }
+    };
+
+    // Scheduling (phase profiles of experiment builds, c3 at traceDepth 4): the services SHADE and END cost ~10^3
+    // instructions each, the same for 1 lane or 64.  Serving as soon as 16 lanes wait ran them at 30-40 % lane utilisation
+    // and 65 % of the drain's time; serving only when NO lane can walk (strict generations) ran them at 90-99 % but left the
+    // wave waiting for its few longest walks (51 % of the time at 7 walking lanes).  So: a service runs when park_end lanes
+    // wait for it, or when nobody walks.
+    const uint32_t park_end = s.park_end;
     for (;;) {
-        // ---- refill idle lanes from the queue ----
-        if (next < count) {
-            const uint64_t idle = __ballot(st == IDLE);
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (n_idle >= park_end || (n_idle != 0u && __ballot(st == WALK) == 0ull)) {
-                PROF_BEGIN(pr, PH_REFILL);
-                const uint32_t i = next + lane_rank(idle);
-                if (st == IDLE && i < count) {
-                    const uint32_t* p = Q.q + i;
-                    const uint32_t cap = Q.cap;
-                    vs.pt = V3(u2f(p[0]), u2f(p[cap]), u2f(p[2 * cap]));
-                    vs.wo = V3(u2f(p[3 * cap]), u2f(p[4 * cap]), u2f(p[5 * cap]));
-                    val = u2f(p[6 * cap]);
-                    rng.v0 = p[7 * cap]; rng.v1 = p[8 * cap]; rng.v2 = p[9 * cap]; rng.v3 = p[10 * cap]; rng.v4 = p[11 * cap]; rng.d = p[12 * cap];
-                    id = p[13 * cap];
-                    L = V3(0.f, 0.f, 0.f); T = V3(1.f, 1.f, 1.f); k = 0u;
-                    st = SHADE;
-                }
-                PROF_END(pr, min(n_idle, count - next));
-                next = min(count, next + n_idle);
-            }
-        }
-        // ---- SHADE: VolumeSample + next-event estimation up to the shadow walk (pathtracer.cu:237-257, 171-191) ----
-        {
-            const uint64_t m = __ballot(st == SHADE);
-            if (m != 0ull && ((uint32_t)__popcll(m) >= park_end || __ballot(st == WALK) == 0ull)) {
-                PROF_BEGIN(ps, PH_SHADE);
-                if (st == SHADE) {
-                    if (COUNT) { c.scatter++; c.taps += 7; c.exec += 6; }
-                    tf_rgba(s, s.tf, val, vs.color);
-                    {
-                        // Gradient_CentralDiff, cuda_volume.h:54-61
-                        const v3 q = vs.pt;
-                        float xd = intensity_at<LAYOUT>(s, V3(q.x + s.spacing[0], q.y + 0.f, q.z + 0.f)) -
-                                   intensity_at<LAYOUT>(s, V3(q.x - s.spacing[0], q.y - 0.f, q.z - 0.f));
-                        float yd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + s.spacing[1], q.z + 0.f)) -
-                                   intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - s.spacing[1], q.z - 0.f));
-                        float zd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + 0.f, q.z + s.spacing[2])) -
-                                   intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - 0.f, q.z - s.spacing[2]));
-                        vs.gradient = V3((xd * 0.5f) * s.invSpacing[0], (yd * 0.5f) * s.invSpacing[1], (zd * 0.5f) * s.invSpacing[2]);
-                    }
-                    const float gradMag = __builtin_sqrtf(dot(vs.gradient, vs.gradient));
-                    vs.Pbrdf = vs.color[3] * (1.f - expf_(s.pbrdf_c * gradMag * 65535.f * s.invMaxMagnitude));
-                    vs.st = (rng_uniform(rng) < vs.Pbrdf) ? 1 : 0;
-                    // estimate_direct_light, pathtracer.cu:171-198
-                    have_light = false;
-                    orig = vs.pt;
-                    st = END; shadow = true; hit = false;
-                    if (s.num_lights != 0) {
-                        int li = (int)((float)s.num_lights * rng_uniform(rng));
-                        li = li < (int)s.num_lights ? li : (int)s.num_lights - 1;
-                        v3 wiL, Li;
-                        if (sample_light(s.lights[li], vs.pt, rng, wiL, pdfL, Li)) {
-                            have_light = true;
-                            lightId = (uint32_t)li;
-                            B = bsdf_eval(vs, wiL);
-                            if (COUNT) c.shadow++;
-                            dir = wiL;
-                            // the draws of sample_bsdf / roulette follow the shadow walk unless this is the last bounce
-                            begin_walk(true, k + 1u < traceDepth);
-                        }
-                    }
-                }
-                PROF_END(ps, (uint32_t)__popcll(m));
-            }
-        }
-        // ---- cheap phase: Woodcock iterations without a fetch (woodcock_tracking.h:32-45) ----
+        // ---- WALK: iterations of every walking lane, fetches and re-marches served as they come, until every walk is over ----
+        PROF_BEGIN(pw, PH_CHEAP);
 #if SVR_PROF
-        const uint64_t tc0 = __builtin_amdgcn_s_memtime();
         uint32_t pc_it = 0u, pc_walk = 0u;
 #endif
-        for (;;) {
+        while (__ballot(st == WALK) != 0ull) {
+            if ((uint32_t)__popcll(__ballot(st == END)) >= park_end) break;
+            if ((uint32_t)__popcll(__ballot(st == SHADE || (st == IDLE && next < count))) >= park_end) break;
 #if SVR_PROF
             pc_it++; pc_walk += (uint32_t)__popcll(__ballot(st == WALK));
 #endif
-            if (st == WALK) {
-                if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; }
-                t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-                if (t > tMax || guard++ >= SVR_WALK_GUARD) st = END;
-                else {
-                    if (COUNT) c.taps++;
-                    if (SKIP && t < t_occ) {
-                        if (COUNT && !(ray_skippable || tail_counted)) c.ipre++;
-                        rng_skip(rng);                                  // the accept draw of a FREE iteration
-                    } else {
-                        const Cell cell = cell_of(s, orig + dir * t);
-                        CellInfo ci;
-                        ci.empty = false; ci.deep = false; ci.thr = INF;
-                        if (SKIP) ci = cell_info<true>(L_, s, cell);
-                        if (ci.empty) {
-                            rng_skip(rng);                              // sigma_t = 0: the draw is consumed, the test fails
-                            clear_run = ci.deep ? clear_run + 1u : 0u;
-                            if (clear_run == 2u) st = MARCH;
-                        } else {
-                            clear_run = 0u;
-                            xi = rng_uniform(rng);
-                            if (xi < ci.thr) st = FETCH;               // else CULLED: xi >= bound >= sigma_t * invSigmaMax
-                            else if (COUNT) c.cull++;
-                        }
+            if (st == WALK) iterate();
+            // FETCH: 8 voxels + filter + LUT, then the accept test with the draw the lane kept
+            if (__ballot(st == FETCH) != 0ull) {
+                if (st == FETCH) {
+                    if (COUNT) c.exec++;
+                    val = tex_fetch<LAYOUT>(s, cell_of(s, orig + dir * t)) * s.densityScale;
+                    const float sigma_t = alpha_of(L_, s, val);
+                    if (xi < sigma_t * s.invSigmaMax) { st = END; hit = true; }
+                    else st = WALK;
+                }
+            }
+            // MARCH: the walk has left an occupied stretch: where is the next one?
+            if (SKIP && __ballot(st == MARCH) != 0ull) {
+                if (st == MARCH) {
+                    t_occ = first_occupied(s, L_, orig, dir, t, tMax);
+                    clear_run = 0u;
+                    st = WALK;
+                    if (t_occ == INF && !rng_live) {
+                        if (!COUNT) st = END;                           // nothing ahead and no draw follows the walk: it ends without a collision
+                        else if (!tail_counted) { tail_counted = true; c.wskip++; }
                     }
                 }
             }
-            if (__ballot(st == WALK) == 0ull) break;
-            if ((uint32_t)__popcll(__ballot(st == FETCH || st == MARCH)) >= park_min) break;
-            if ((uint32_t)__popcll(__ballot(st == END || st == SHADE || (st == IDLE && next < count))) >= park_end) break;
         }
 #if SVR_PROF
-        {
-            const uint64_t dt = __builtin_amdgcn_s_memtime() - tc0;
-            if ((threadIdx.x & 63u) == 0u) {
-                atomicAdd(&c_prof[2 * PH_CHEAP], (unsigned long long)dt);
-                atomicAdd(&c_prof[2 * PH_CHEAP + 1], (unsigned long long)(pc_it ? dt * pc_walk / pc_it : 0));
-                atomicAdd(&c_prof[2 * PH_N], (unsigned long long)pc_it);
-                atomicAdd(&c_prof[2 * PH_N + 1], (unsigned long long)pc_walk);
-            }
-        }
-        const uint64_t m_fetch = __ballot(st == FETCH), m_march = __ballot(st == MARCH);
+        PROF_END(pw, pc_it ? pc_walk / pc_it : 0u);
+        if ((threadIdx.x & 63u) == 0u) { atomicAdd(&c_prof[2 * PH_N], (unsigned long long)pc_it); atomicAdd(&c_prof[2 * PH_N + 1], (unsigned long long)pc_walk); }
 #endif
-        // ---- FETCH / MARCH services ----
-        PROF_BEGIN(pf, PH_FETCH);
-        if (st == FETCH) {
-            if (COUNT) c.exec++;
-            val = tex_fetch<LAYOUT>(s, cell_of(s, orig + dir * t)) * s.densityScale;
-            const float sigma_t = alpha_of(L_, s, val);
-            if (xi < sigma_t * s.invSigmaMax) { st = END; hit = true; }
-            else st = WALK;
-        }
-#if SVR_PROF
-        if (m_fetch) PROF_END(pf, (uint32_t)__popcll(m_fetch));
-#endif
-        PROF_BEGIN(pm, PH_MARCH);
-        if (SKIP && st == MARCH) {
-            t_occ = first_occupied(s, L_, orig, dir, t, tMax);
-            clear_run = 0u;
-            st = WALK;
-            if (t_occ == INF && !rng_live) {
-                if (!COUNT) st = END;                                   // nothing ahead and no draw follows the walk: it ends without a collision
-                else if (!tail_counted) { tail_counted = true; c.wskip++; }
-            }
-        }
-#if SVR_PROF
-        if (m_march) PROF_END(pm, (uint32_t)__popcll(m_march));
-#endif
-        // ---- END: a walk is over ----
+        const bool walking = __ballot(st == WALK) != 0ull;
+        // ---- END: walks that are over ----
         {
             const uint64_t m = __ballot(st == END);
-            if (m != 0ull && ((uint32_t)__popcll(m) >= park_end || __ballot(st == WALK || st == FETCH || st == MARCH) == 0ull)) {
+            if (m != 0ull && (!walking || (uint32_t)__popcll(m) >= park_end)) {
                 PROF_BEGIN(pe, PH_END);
                 if (st == END) {
                     bool finished = false;
@@ -308,9 +238,76 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
                     }
                 }
                 PROF_END(pe, (uint32_t)__popcll(m));
+                if (__ballot(st == WALK) != 0ull) continue;            // the next bounce's walks first: their hits join the shading below
             }
         }
-        if (next >= count && __ballot(st != IDLE) == 0ull) break;
+        const bool shade_now = !walking || (uint32_t)__popcll(__ballot(st == SHADE || (st == IDLE && next < count))) >= park_end;
+        // ---- refill the idle lanes from the queue ----
+        if (next < count && shade_now) {
+            const uint64_t idle = __ballot(st == IDLE);
+            if (idle != 0ull) {
+                PROF_BEGIN(pr, PH_REFILL);
+                const uint32_t n_idle = (uint32_t)__popcll(idle);
+                const uint32_t i = next + lane_rank(idle);
+                if (st == IDLE && i < count) {
+                    const uint32_t* p = Q.q + i;
+                    const uint32_t cap = Q.cap;
+                    vs.pt = V3(u2f(p[0]), u2f(p[cap]), u2f(p[2 * cap]));
+                    vs.wo = V3(u2f(p[3 * cap]), u2f(p[4 * cap]), u2f(p[5 * cap]));
+                    val = u2f(p[6 * cap]);
+                    rng.v0 = p[7 * cap]; rng.v1 = p[8 * cap]; rng.v2 = p[9 * cap]; rng.v3 = p[10 * cap]; rng.v4 = p[11 * cap]; rng.d = p[12 * cap];
+                    id = p[13 * cap];
+                    L = V3(0.f, 0.f, 0.f); T = V3(1.f, 1.f, 1.f); k = 0u;
+                    st = SHADE;
+                }
+                PROF_END(pr, min(n_idle, count - next));
+                next = min(count, next + n_idle);
+            }
+        }
+        // ---- SHADE: VolumeSample + next-event estimation up to the shadow walk (pathtracer.cu:237-257, 171-191) ----
+        {
+            const uint64_t m = __ballot(st == SHADE);
+            if (m == 0ull && !walking && __ballot(st != IDLE) == 0ull) break;   // no walk, no end, no record, nothing to shade: the queue is drained
+            if (m == 0ull || !shade_now) continue;
+            PROF_BEGIN(ps, PH_SHADE);
+            if (st == SHADE) {
+                if (COUNT) { c.scatter++; c.taps += 7; c.exec += 6; }
+                tf_rgba(s, s.tf, val, vs.color);
+                {
+                    // Gradient_CentralDiff, cuda_volume.h:54-61
+                    const v3 q = vs.pt;
+                    float xd = intensity_at<LAYOUT>(s, V3(q.x + s.spacing[0], q.y + 0.f, q.z + 0.f)) -
+                               intensity_at<LAYOUT>(s, V3(q.x - s.spacing[0], q.y - 0.f, q.z - 0.f));
+                    float yd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + s.spacing[1], q.z + 0.f)) -
+                               intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - s.spacing[1], q.z - 0.f));
+                    float zd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + 0.f, q.z + s.spacing[2])) -
+                               intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - 0.f, q.z - s.spacing[2]));
+                    vs.gradient = V3((xd * 0.5f) * s.invSpacing[0], (yd * 0.5f) * s.invSpacing[1], (zd * 0.5f) * s.invSpacing[2]);
+                }
+                const float gradMag = __builtin_sqrtf(dot(vs.gradient, vs.gradient));
+                vs.Pbrdf = vs.color[3] * (1.f - expf_(s.pbrdf_c * gradMag * 65535.f * s.invMaxMagnitude));
+                vs.st = (rng_uniform(rng) < vs.Pbrdf) ? 1 : 0;
+                // estimate_direct_light, pathtracer.cu:171-198
+                have_light = false;
+                orig = vs.pt;
+                st = END; shadow = true; hit = false;
+                if (s.num_lights != 0) {
+                    int li = (int)((float)s.num_lights * rng_uniform(rng));
+                    li = li < (int)s.num_lights ? li : (int)s.num_lights - 1;
+                    v3 wiL, Li;
+                    if (sample_light(s.lights[li], vs.pt, rng, wiL, pdfL, Li)) {
+                        have_light = true;
+                        lightId = (uint32_t)li;
+                        B = bsdf_eval(vs, wiL);
+                        if (COUNT) c.shadow++;
+                        dir = wiL;
+                        // the draws of sample_bsdf / roulette follow the shadow walk unless this is the last bounce
+                        begin_walk(true, k + 1u < traceDepth);
+                    }
+                }
+            }
+            PROF_END(ps, (uint32_t)__popcll(m));
+        }
     }
 }
 
