@@ -208,6 +208,9 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
                                      media without exactly transparent space, 2 always.  Results identical */
 #define SVR_OPT_FOLD 17             /* 1 (default): a many-frame launch of the tile kernel folds its frames into the HDR accumulator itself (running
                                      mean in frame order, in the wave that traced them); 0: scratch slot per frame + resolve kernel */
+#define SVR_OPT_FAST_MATH 14        /* OPT-IN, default 0: the tile kernel's fast-math build (v_log_f32 in the walk, reciprocal division, fma contraction;
+                                     in the spirit of the reference's -use_fast_math, CMakeLists.txt:9-10).  NOT bit-identical to the default mode:
+                                     converged images agree within Monte-Carlo noise (tests/test_fast_math_gpu.py) */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */

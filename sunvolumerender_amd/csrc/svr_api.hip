@@ -33,6 +33,8 @@ static_assert(sizeof(svr_environment_light) == 32 && offsetof(svr_environment_li
 static_assert(sizeof(svr_render_params) == 16 && offsetof(svr_render_params, hdrBuffer) == 8, "RenderParams layout");
 static_assert(sizeof(svr_counters) == 8 * svr::CNT_N, "counter block");
 
+namespace svr_fast { hipError_t launch_trace_tile_raw(const void* scene, const void* work, const void* cfg, hipStream_t st); }   // svr_trace_tile_fast.hip
+
 namespace {
 
 enum TexKind { TEX_VOLUME = 1, TEX_TF = 2, TEX_ENV = 3 };
@@ -113,7 +115,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 1, opt_park_end = 24, opt_fold = 1, opt_queue = 1;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 1, opt_park_end = 24, opt_fold = 1, opt_queue = 1, opt_fast_math = 0;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint8_t* d_mask_tmp = nullptr;     // scratch of the distance transform
@@ -575,7 +577,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
             slot = g.ev_head;
             HIP_TRY(hipEventRecord(g.ev0[slot], g.stream));
         }
-        HIP_TRY(svr::launch_trace_tile(s, w, cfg, g.stream));
+        HIP_TRY(g.opt_fast_math ? svr_fast::launch_trace_tile_raw(&s, &w, &cfg, g.stream) : svr::launch_trace_tile(s, w, cfg, g.stream));
         if (g.opt_timing) {
             HIP_TRY(hipEventRecord(g.ev1[slot], g.stream));
             g.ev_head = (g.ev_head + 1) % Context::EV_RING;
@@ -616,7 +618,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         }
         if (cfg.kernel == svr::KERNEL_WAVEFRONT)
             HIP_TRY(svr::launch_wavefront(s, w, cfg, set.planes, set.wf_counts, (uint32_t)g.queue_capacity, ts));
-        else if (cfg.kernel == svr::KERNEL_TILE) HIP_TRY(svr::launch_trace_tile(s, w, cfg, ts));
+        else if (cfg.kernel == svr::KERNEL_TILE) HIP_TRY(g.opt_fast_math ? svr_fast::launch_trace_tile_raw(&s, &w, &cfg, ts) : svr::launch_trace_tile(s, w, cfg, ts));
         else HIP_TRY(svr::launch_pathtrace(s, w, cfg, ts));
         if (g.opt_timing) {
             HIP_TRY(hipEventRecord(g.ev1[slot], ts));
@@ -1092,6 +1094,7 @@ int svr_set_option(int key, int value)
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_BOUND_CULL: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_bound_cull = value; return 0;
     case SVR_OPT_FOLD: g.opt_fold = value ? 1 : 0; return 0;
+    case SVR_OPT_FAST_MATH: g.opt_fast_math = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_QUEUE:
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_QUEUE: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_queue = value; return 0;
@@ -1134,6 +1137,7 @@ int svr_get_option(int key)
     case SVR_OPT_RAY_SKIP: return g.opt_ray_skip;
     case SVR_OPT_BOUND_CULL: return g.opt_bound_cull;
     case SVR_OPT_FOLD: return g.opt_fold;
+    case SVR_OPT_FAST_MATH: return g.opt_fast_math;
     case SVR_OPT_QUEUE: return g.opt_queue;
     case SVR_OPT_PARK_END: return g.opt_park_end;
     case SVR_OPT_PARK_MIN: return g.opt_park_min;

@@ -25,6 +25,18 @@ SVR_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); 
 #define SVR_NAN_BITS 0x7fc00000u
 #define SVR_FLT_MAX 3.402823466e+38f
 
+#ifdef SVR_FAST_MATH
+// OPT-IN fast-math build of the trace kernel (svr_trace_tile_fast.hip, SVR_OPT_FAST_MATH): the hardware's v_log_f32 for
+// the logarithms (the Woodcock walk's -log(1 - xi) is the dominant transcendental: one per iteration) and, through the
+// TU's compile flags, reciprocal-based division and fma contraction -- in the spirit of the reference's nvcc
+// -use_fast_math (CMakeLists.txt:9-10).  Level 2 (SVR_FAST_MATH >= 2) also swaps exp / sin / cos / pow for v_exp_f32 /
+// v_sin_f32 / v_cos_f32; it is not built: the shorter code lets the scheduler overlap more and spills ~50 VGPRs (-38 %).
+// Results are no longer bit-identical to the oracle; the contract for this mode is the converged-image tolerance of
+// tests/test_fast_math_gpu.py.
+SVR_DEV float logf_(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+SVR_DEV float logf_unit(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
+#else
 SVR_DEV float logf_(float x)
 {
     if (x != x) return x;
@@ -91,6 +103,18 @@ SVR_DEV float logf_unit(float x)
     // x == 0 -> -inf; subnormal x cannot occur (1-u is a multiple of 2^-25 or 0)
     return x == 0.f ? u2f(0xff800000u) : r;
 }
+#endif // SVR_FAST_MATH (logarithms)
+
+#if defined(SVR_FAST_MATH) && SVR_FAST_MATH >= 2
+SVR_DEV float expf_(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+SVR_DEV void sincosf_(float x, float* s_out, float* c_out)
+{
+    const float r = x * 0.15915494309189535f;          // v_sin_f32 / v_cos_f32 take revolutions
+    *s_out = __builtin_amdgcn_sinf(r);
+    *c_out = __builtin_amdgcn_cosf(r);
+}
+SVR_DEV float powf_(float x, float y) { return y == 0.f ? 1.f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#else
 
 SVR_DEV float expf_(float x)
 {
@@ -160,6 +184,7 @@ SVR_DEV float powf_(float x, float y)
     if (x < 0.f) return u2f(SVR_NAN_BITS);
     return expf_(y * logf_(x));
 }
+#endif // SVR_FAST_MATH
 
 SVR_DEV float asinf_core(float a)
 {

@@ -385,11 +385,13 @@ SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rn
     if (COUNT && ray_skippable) c.wskip++;
     bool tail_counted = false;          // COUNT builds only: a non-counting build would have ended the walk
     uint32_t guard = 0;
+    #pragma nounroll
     for (;;) {
         // ---- prefix: iterations before the first possibly-occupied macro-cell.  No fetch, sigma_t = 0: each is a
         //      distance draw + log, the exit test, and the state update of the accept draw (its value is unused) ----
         bool pending = false;           // t has been advanced and still needs its tap and accept draw
         if (SKIP) {
+            #pragma nounroll
             for (;;) {
                 if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; else c.ipre++; }
                 t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
@@ -401,6 +403,7 @@ SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rn
         }
         // ---- general iterations (loop rotated: tap first, then advance) ----
         uint32_t clear_run = 0;
+        #pragma nounroll
         for (;;) {
             if (!pending) {
                 if (COUNT) { c.iters++; if (tail_counted) c.iskip++; }
