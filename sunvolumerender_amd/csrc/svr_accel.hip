@@ -139,6 +139,15 @@ __global__ __launch_bounds__(256) void k_bound_class(const uint16_t* __restrict_
     }
 }
 
+hipError_t launch_fine_mask(const uint16_t* mm, uint32_t n_cells, const uint32_t* tf_zero_prefix, int tf_n, float densityScale,
+                            uint32_t* mask, uint32_t words, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(mask, 0, (size_t)words * 4u, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_empty_mask, dim3((n_cells + 255u) / 256u), dim3(256), 0, st, mm, n_cells, tf_zero_prefix, tf_n, densityScale, mask);
+    return hipGetLastError();
+}
+
 hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const float* tf_rgba, int tf_n, float densityScale,
                               float invSigmaMax, uint32_t* accel, hipStream_t st)
 {

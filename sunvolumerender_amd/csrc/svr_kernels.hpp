@@ -52,6 +52,9 @@ hipError_t launch_minmax(const uint16_t* src_linear, uint16_t* mm, int nx, int n
 // bits; tmp: 2 * gx*gy*gz bytes of scratch
 hipError_t launch_empty_mask(const uint16_t* mm, int gx, int gy, int gz, const uint32_t* tf_zero_prefix, int tf_n,
                              float densityScale, uint32_t* mask, uint32_t mask_words, uint8_t* tmp, hipStream_t stream);
+// `empty` bits of a (fine) macro-cell level into plain global memory: mask[n_cells / 32]
+hipError_t launch_fine_mask(const uint16_t* mm, uint32_t n_cells, const uint32_t* tf_zero_prefix, int tf_n, float densityScale,
+                            uint32_t* mask, uint32_t words, hipStream_t stream);
 // bound classes of the half-resolution macro-cells (4 bit each) + the BOUND_CLASSES thresholds, into accel + ACCEL_CLASS_OFF
 hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const float* tf_rgba, int tf_n, float densityScale,
                               float invSigmaMax, uint32_t* accel, hipStream_t stream);

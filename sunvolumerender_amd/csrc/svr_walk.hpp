@@ -173,6 +173,13 @@ SVR_DEV CellInfo cell_info(const LDS& L, const DevScene& s, const Cell& c)
     m = inb ? m : 0u;
     CellInfo r;
     r.empty = inb && ((L.emask[m >> 5] >> (m & 31u)) & 1u);
+    if (s.fine_mask != nullptr && inb && !r.empty) {
+        // the coarse cell holds something somewhere: ask the fine level (cells of half the edge, global memory) about this spot
+        const uint32_t fs = sh - 1u;
+        const uint32_t fx = min(ux >> fs, (uint32_t)s.fg_x - 1u), fy = min(uy >> fs, (uint32_t)s.fg_y - 1u), fz = min(uz >> fs, (uint32_t)s.fg_z - 1u);
+        const uint32_t f = fx + fy * (uint32_t)s.fg_x + fz * (uint32_t)s.fg_xy;
+        r.empty = (s.fine_mask[f >> 5] >> (f & 31u)) & 1u;
+    }
     r.deep = WANT_DEEP ? (inb && ((L.mask[m >> 5] >> (m & 31u)) & 1u)) : false;
     r.thr = u2f(SVR_INF_BITS);
     if constexpr (lds_has_cull<LDS>::value) {
