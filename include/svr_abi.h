@@ -148,6 +148,8 @@ void svr_clear_error(void);
 #define SVR_LAYOUT_AUTO 0
 #define SVR_LAYOUT_LINEAR 1          /* [z][y][x] with a 2-voxel zero apron */
 #define SVR_LAYOUT_BRICK 2           /* 8x4x4-voxel bricks (256 B), 2-voxel zero apron */
+#define SVR_LAYOUT_PAIR 3            /* the same bricks with 32-bit elements: voxel x | voxel x+1 << 16 (half the gather instructions per
+                                        trilinear fetch, twice the memory); volumes up to ~1000^3; what AUTO picks when it fits */
 uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz,
                                    int src_is_device, int layout);
 /* gui/transferfunction.cpp:30-44 (1D float4 array, clamp / linear / normalized coords). */
@@ -214,6 +216,8 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
 #define SVR_OPT_FINE_MASK 20        /* second, finer level of `empty` macro-cells (half the edge) in global memory for the per-fetch test:
                                      0 (default) off, 1 when the LDS-resident cells are >= 16 voxels (volumes beyond 512^3), 2 whenever it exists.
                                      Fewer fetches (c5: 3.9 instead of 5.9 per path), same speed: the test costs a dependent cached load */
+#define SVR_OPT_ROW_ORDER 21        /* tile kernel work distribution: 1 = each of the 8 ticket counters (one per XCD group of blocks) owns whole tile
+                                     rows, so neighbouring tiles share an XCD's L2; 0 = every 8th task.  Speed only */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */

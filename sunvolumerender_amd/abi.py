@@ -130,7 +130,7 @@ for _t, _n in EXPECTED_SIZES.items():
 MAX_LIGHT_SOURCES = 8
 TF_TABLE_SIZE = 1024
 
-LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_BRICK = 0, 1, 2
+LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_BRICK, LAYOUT_PAIR = 0, 1, 2, 3
 OPT_ENV_ON_ESCAPE, OPT_KERNEL, OPT_COUNT, OPT_TIMING, OPT_SKIP_TONEMAP, OPT_BLOCKS_PER_CU = 1, 2, 3, 4, 5, 6
 OPT_PIPELINE, OPT_REFILL_MIN_IDLE, OPT_EMPTY_SKIP, OPT_RAY_SKIP, OPT_FRAMES_PER_WAVE_LOG2 = 7, 8, 9, 10, 11
 OPT_RAYCAST_LANES_LOG2 = 12
@@ -142,6 +142,7 @@ OPT_FOLD = 17
 OPT_QUEUE = 18
 OPT_PARK_END = 19
 OPT_FINE_MASK = 20
+OPT_ROW_ORDER = 21
 KERNEL_AUTO, KERNEL_PIXEL, KERNEL_TILE, KERNEL_ULOOP, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4
 
 ELEM_I8, ELEM_U8, ELEM_I16, ELEM_U16, ELEM_I32, ELEM_U32, ELEM_F32, ELEM_F64 = range(8)

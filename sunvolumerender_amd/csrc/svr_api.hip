@@ -119,7 +119,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 1, opt_park_end = 24, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 1, opt_park_end = 24, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -342,6 +342,7 @@ int fill_work(svr::DevWork& w, uint32_t W, uint32_t H)
     w.ticket = g.d_ticket;
     w.refill_min_idle = (uint32_t)g.opt_refill;
     w.debug_stop = (uint32_t)g.opt_debug_stop;
+    w.row_order = (uint32_t)g.opt_row_order;
     w.strip_rows = g.strip_rows ? g.strip_rows : 1;
     w.rank = g.rank;
     w.world = g.world;
@@ -813,13 +814,17 @@ uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int n
 {
     if (ensure_init()) return 0;
     if (!voxels || nx <= 0 || ny <= 0 || nz <= 0) { fail(-6, "svr_create_volume_texture: bad arguments (%p, %d, %d, %d)", (const void*)voxels, nx, ny, nz); return 0; }
-    if (layout != SVR_LAYOUT_AUTO && layout != SVR_LAYOUT_LINEAR && layout != SVR_LAYOUT_BRICK) { fail(-6, "svr_create_volume_texture: unknown layout %d", layout); return 0; }
+    if (layout != SVR_LAYOUT_AUTO && layout != SVR_LAYOUT_LINEAR && layout != SVR_LAYOUT_BRICK && layout != SVR_LAYOUT_PAIR) { fail(-6, "svr_create_volume_texture: unknown layout %d", layout); return 0; }
     {
         // BRICK needs 24-bit brick-row / brick-slab strides (svr_trace_tile.hip); AUTO picks it when they fit
         size_t bx = ((size_t)nx + 2 * svr::VOL_PAD + svr::BRICK_X - 1) / svr::BRICK_X;
         size_t by = ((size_t)ny + 2 * svr::VOL_PAD + svr::BRICK_Y - 1) / svr::BRICK_Y;
         bool brick_ok = (bx * by * 256) < ((size_t)1 << 24);
-        if (layout == SVR_LAYOUT_AUTO) layout = brick_ok ? SVR_LAYOUT_BRICK : SVR_LAYOUT_LINEAR;
+        // PAIR: the same bricks with 32-bit elements -- strides and byte offsets double
+        const size_t bz_ = ((size_t)nz + 2 * svr::VOL_PAD + svr::BRICK_Z - 1) / svr::BRICK_Z;
+        const bool pair_ok = (bx * by * 512) < ((size_t)1 << 24) && bx * by * bz_ * 512 < ((size_t)1 << 32);
+        if (layout == SVR_LAYOUT_AUTO) layout = pair_ok ? SVR_LAYOUT_PAIR : (brick_ok ? SVR_LAYOUT_BRICK : SVR_LAYOUT_LINEAR);
+        if (layout == SVR_LAYOUT_PAIR && !pair_ok) { fail(-6, "svr_create_volume_texture: %dx%dx%d is too large for the PAIR layout (32-bit byte offsets); use BRICK", nx, ny, nz); return 0; }
         if (layout == SVR_LAYOUT_BRICK && !brick_ok) { fail(-6, "svr_create_volume_texture: %dx%d slices are too large for the BRICK layout; use LINEAR", nx, ny); return 0; }
     }
     Texture* t = new Texture();
@@ -843,7 +848,7 @@ uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int n
             if (gx * gy * gz <= (size_t)svr::MASK_WORDS_MAX * 32) { t->mc_shift = sh; t->mc_gx = (int)gx; t->mc_gy = (int)gy; t->mc_gz = (int)gz; break; }
         }
     }
-    t->bytes = elems * sizeof(uint16_t);
+    t->bytes = elems * (layout == SVR_LAYOUT_PAIR ? sizeof(uint32_t) : sizeof(uint16_t));
     size_t src_bytes = (size_t)nx * ny * nz * sizeof(uint16_t);
     const uint16_t* d_src = voxels;
     uint16_t* staged = nullptr;
@@ -1124,6 +1129,7 @@ int svr_set_option(int key, int value)
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_BOUND_CULL: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_bound_cull = value; return 0;
     case SVR_OPT_FOLD: g.opt_fold = value ? 1 : 0; return 0;
+    case SVR_OPT_ROW_ORDER: g.opt_row_order = value ? 1 : 0; return 0;
     case SVR_OPT_FINE_MASK:
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_FINE_MASK: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_fine_mask = value; return 0;
@@ -1170,6 +1176,7 @@ int svr_get_option(int key)
     case SVR_OPT_RAY_SKIP: return g.opt_ray_skip;
     case SVR_OPT_BOUND_CULL: return g.opt_bound_cull;
     case SVR_OPT_FOLD: return g.opt_fold;
+    case SVR_OPT_ROW_ORDER: return g.opt_row_order;
     case SVR_OPT_FINE_MASK: return g.opt_fine_mask;
     case SVR_OPT_FAST_MATH: return g.opt_fast_math;
     case SVR_OPT_QUEUE: return g.opt_queue;

@@ -94,6 +94,19 @@ SVR_DEV float tex3d(const DevScene& s, float u, float v, float w)
         v010 = (float)p1[0]; v110 = (float)p1[1];
         v001 = (float)p2[0]; v101 = (float)p2[1];
         v011 = (float)p3[0]; v111 = (float)p3[1];
+    } else if (LAYOUT == LAYOUT_PAIR) {
+        // 32-bit elements: voxel x | voxel x + 1 << 16 (svr_walk.hpp, tex_fetch)
+        int j1 = j + 1, k1 = k + 1;
+        int X0 = ((i >> 3) << 7) + (i & 7);
+        int Y0 = (j >> 2) * (s.bnx << 7) + ((j & 3) << 3), Y1 = (j1 >> 2) * (s.bnx << 7) + ((j1 & 3) << 3);
+        int zs = (s.bny * s.bnx) << 7;
+        int Z0 = (k >> 2) * zs + ((k & 3) << 5), Z1 = (k1 >> 2) * zs + ((k1 & 3) << 5);
+        const uint32_t* __restrict__ pv = reinterpret_cast<const uint32_t*>(vox);
+        const uint32_t p00 = pv[Y0 + Z0 + X0], p10 = pv[Y1 + Z0 + X0], p01 = pv[Y0 + Z1 + X0], p11 = pv[Y1 + Z1 + X0];
+        v000 = (float)(p00 & 0xffffu); v100 = (float)(p00 >> 16);
+        v010 = (float)(p10 & 0xffffu); v110 = (float)(p10 >> 16);
+        v001 = (float)(p01 & 0xffffu); v101 = (float)(p01 >> 16);
+        v011 = (float)(p11 & 0xffffu); v111 = (float)(p11 >> 16);
     } else {
         int i1 = i + 1, j1 = j + 1, k1 = k + 1;
         int X0 = ((i >> 3) << 7) + (i & 7), X1 = ((i1 >> 3) << 7) + (i1 & 7);

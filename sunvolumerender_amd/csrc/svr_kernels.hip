@@ -483,6 +483,26 @@ __global__ __launch_bounds__(256) void k_repack(const uint16_t* __restrict__ src
     }
 }
 
+// PAIR layout: element (i, j, k) of the padded brick grid = voxel x | voxel (x + 1) << 16 (x = i - VOL_PAD; voxels
+// outside the volume are border texels = 0); dst (32-bit elements) must be zero-filled before the launch
+__global__ __launch_bounds__(256) void k_repack_pair(const uint16_t* __restrict__ src, uint32_t* __restrict__ dst, int nx, int ny, int nz, int bnx, int bny)
+{
+    const size_t ex = (size_t)nx + 1;                      // x = -1 .. nx - 1 have a non-zero half
+    const size_t n = ex * ny * nz;
+    for (size_t e = (size_t)blockIdx.x * 256u + threadIdx.x; e < n; e += (size_t)gridDim.x * 256u) {
+        const int x = (int)(e % ex) - 1;
+        const size_t rest = e / ex;
+        const int y = (int)(rest % (size_t)ny), z = (int)(rest / (size_t)ny);
+        const size_t row = ((size_t)z * ny + y) * nx;
+        const uint32_t lo = x >= 0 ? src[row + x] : 0u, hi = x + 1 < nx ? src[row + x + 1] : 0u;
+        const int i = x + VOL_PAD, j = y + VOL_PAD, k = z + VOL_PAD;
+        const size_t X = ((size_t)(i >> 3) << 7) + (size_t)(i & 7);
+        const size_t Y = (size_t)(j >> 2) * ((size_t)bnx << 7) + (size_t)((j & 3) << 3);
+        const size_t Z = (size_t)(k >> 2) * (((size_t)bny * bnx) << 7) + (size_t)((k & 3) << 5);
+        dst[X + Y + Z] = lo | (hi << 16);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -509,6 +529,8 @@ static hipError_t launch_pathtrace_t(const DevScene& s, const DevWork& w, const 
 
 hipError_t launch_pathtrace(const DevScene& s, const DevWork& w, const LaunchCfg& cfg, hipStream_t st)
 {
+    if (s.layout == LAYOUT_PAIR)
+        return cfg.count ? launch_pathtrace_t<LAYOUT_PAIR, true>(s, w, cfg, st) : launch_pathtrace_t<LAYOUT_PAIR, false>(s, w, cfg, st);
     if (s.layout == LAYOUT_LINEAR)
         return cfg.count ? launch_pathtrace_t<LAYOUT_LINEAR, true>(s, w, cfg, st) : launch_pathtrace_t<LAYOUT_LINEAR, false>(s, w, cfg, st);
     return cfg.count ? launch_pathtrace_t<LAYOUT_BRICK, true>(s, w, cfg, st) : launch_pathtrace_t<LAYOUT_BRICK, false>(s, w, cfg, st);
@@ -533,6 +555,10 @@ hipError_t launch_tonemap(const DevScene& s, const DevWork& w, hipStream_t st)
 hipError_t launch_repack(const uint16_t* src, uint16_t* dst, int nx, int ny, int nz, int layout,
                          int sy, int sz, int bnx, int bny, hipStream_t st)
 {
+    if (layout == LAYOUT_PAIR) {
+        hipLaunchKernelGGL(k_repack_pair, dim3(4096), dim3(256), 0, st, src, reinterpret_cast<uint32_t*>(dst), nx, ny, nz, bnx, bny);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_repack, dim3(4096), dim3(256), 0, st, src, dst, nx, ny, nz, layout, sy, sz, bnx, bny);
     return hipGetLastError();
 }

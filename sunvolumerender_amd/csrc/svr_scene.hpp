@@ -8,7 +8,7 @@
 namespace svr {
 
 // volume memory layouts (software "texture"; gfx950 exposes no image/sampler path to HIP)
-enum { LAYOUT_LINEAR = 1, LAYOUT_BRICK = 2 };
+enum { LAYOUT_LINEAR = 1, LAYOUT_BRICK = 2, LAYOUT_PAIR = 3 };   // PAIR: BRICK with 32-bit elements (voxel x | voxel x + 1 << 16)
 constexpr int VOL_PAD = 2;         // zero apron, voxels, each side (border addressing)
 constexpr int BRICK_X = 8, BRICK_Y = 4, BRICK_Z = 4;   // 8*4*4 u16 = 256 B
 
@@ -97,6 +97,7 @@ struct DevWork {
     uint32_t frames_log2;          // tile kernel: log2(frames per wave); a wave = (64 >> f) pixels x (1 << f) frames
     uint32_t fold;                 // tile kernel: 1 = fold the group's frames into hdr in the kernel (running mean in frame order;
                                    // needs nframes <= 64 so that a pixel's frames sit in one wave); 0 = write the scratch slots
+    uint32_t row_order;            // tile kernel: 1 = a ticket counter owns whole tile rows (XCD-local rows), 0 = every 8th task
     uint32_t debug_stop;           // timing ablation only (0 = off): 1 stop after set-up, 2 after the whole-ray test, 3 after the primary walk
     uint32_t refill_min_idle;      // persistent kernel: regenerate lanes once this many are idle (64 = tile-synchronous)
     unsigned long long* counters;  // svr_counters on the device, or null

@@ -342,14 +342,27 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
             // away from the home counter, look before taking: when the launch runs out, every wave visits every
             // counter once, and 4096 x 8 returning atomics alone took ~45 us (a plain load of a drained counter
             // is free; the counters only grow, so a stale value just means one atomic more)
-            if (si != 0u && __atomic_load_n(ticket, __ATOMIC_RELAXED) * TICKET_SHARDS + shard >= n_units) break;
+            // w.row_order: counter j owns whole TILE ROWS (rows j, j + 8 ... of the centre-out order) instead of every 8th task:
+            // blocks b and b + 8 share an XCD (MI355X_MICROARCH.md), a block starts on counter b % 8, so consecutive tiles of
+            // a row -- whose ray tubes run through the same bricks -- are traced on one XCD and find them in its L2
+            const uint32_t rows_s = (w.row_order && ts.tiles_y > shard) ? (ts.tiles_y - shard + TICKET_SHARDS - 1u) / TICKET_SHARDS : 0u;
+            const uint32_t limit = w.row_order ? rows_s * ts.row_tasks : n_units;
+            if (si != 0u && (w.row_order ? __atomic_load_n(ticket, __ATOMIC_RELAXED) : __atomic_load_n(ticket, __ATOMIC_RELAXED) * TICKET_SHARDS + shard) >= limit) break;
             uint32_t u = 0;
             if (lane == 0) u = atomicAdd(ticket, 1u);
             u = __builtin_amdgcn_readfirstlane(u);
-            const uint32_t unit_id = u * TICKET_SHARDS + shard;
-            if (unit_id >= n_units) break;
-            const uint32_t t_begin = unit_id * unit;
-            const uint32_t t_end = min(t_begin + unit, n_tasks);
+            uint32_t t_begin, t_end;
+            if (w.row_order) {
+                if (u >= limit) break;
+                const uint32_t rq = u / ts.row_tasks;
+                t_begin = (shard + TICKET_SHARDS * rq) * ts.row_tasks + (u - rq * ts.row_tasks);
+                t_end = t_begin + 1u;
+            } else {
+                const uint32_t unit_id = u * TICKET_SHARDS + shard;
+                if (unit_id >= n_units) break;
+                t_begin = unit_id * unit;
+                t_end = min(t_begin + unit, n_tasks);
+            }
             for (uint32_t k = t_begin; k < t_end; ++k) {
                 // k-th task of the centre-out order -> (tile row, tile column, frame group)
                 uint32_t tx, ty, fg;
@@ -445,9 +458,9 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
     if (e != hipSuccess) return e;
     const bool skip = s.empty_mask != nullptr, d1 = w.traceDepth == 1u;
     // QUEUE builds need the per-wave record queues (DevWork.queue, sized for `queue_blocks` blocks) and exist for the BRICK layout only
-    const bool queue = LAYOUT == LAYOUT_BRICK && w.fold && w.queue != nullptr && w.pend != nullptr && blocks <= w.queue_blocks;
+    const bool queue = LAYOUT != LAYOUT_LINEAR && w.fold && w.queue != nullptr && w.pend != nullptr && blocks <= w.queue_blocks;
 #define SVR_LAUNCH_TILE(SK, D1, QU) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, SK, D1, QU>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2)
-    if constexpr (LAYOUT == LAYOUT_BRICK) {
+    if constexpr (LAYOUT != LAYOUT_LINEAR) {
         if (queue) {
             if (skip && d1) SVR_LAUNCH_TILE(true, true, true);
             else if (skip) SVR_LAUNCH_TILE(true, false, true);
@@ -466,6 +479,8 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
 
 hipError_t launch_trace_tile(const DevScene& s, const DevWork& w, const LaunchCfg& cfg, hipStream_t st)
 {
+    if (s.layout == LAYOUT_PAIR)
+        return cfg.count ? launch_tile_t<LAYOUT_PAIR, true>(s, w, cfg, st) : launch_tile_t<LAYOUT_PAIR, false>(s, w, cfg, st);
     if (s.layout == LAYOUT_LINEAR)
         return cfg.count ? launch_tile_t<LAYOUT_LINEAR, true>(s, w, cfg, st) : launch_tile_t<LAYOUT_LINEAR, false>(s, w, cfg, st);
     return cfg.count ? launch_tile_t<LAYOUT_BRICK, true>(s, w, cfg, st) : launch_tile_t<LAYOUT_BRICK, false>(s, w, cfg, st);
