@@ -119,7 +119,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 1, opt_park_end = 24, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 1, opt_park_end = 24, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -575,7 +575,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     // short launches (< FOLD_MIN frames) keep the slots: they end in a tail of a few long tasks that only overlapping launches
     // on several streams hide, and a folding launch cannot overlap its predecessor (measured, 1 frame per call: 0.276 vs 0.366 ms)
     constexpr uint32_t FOLD_MIN = 8;
-    const uint32_t tail_frames = nframes % (uint32_t)Context::GROUP;
+    const uint32_t tail_frames = nframes % (uint32_t)(fold_batch ? g.opt_group_frames : Context::GROUP);
     if ((!fold_batch || frame_ahead_call || (tail_frames != 0 && tail_frames < FOLD_MIN)) &&
         ensure_slots(s.imageW, s.imageH, nframes < (uint32_t)Context::GROUP ? nframes : (uint32_t)Context::GROUP)) return g.err_code;
     // one folding launch: trace + accumulate on the caller's stream (the launches of a render update the same accumulator,
@@ -715,8 +715,10 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         return trace_group(next_set(), n, batch, 1, want_img);
     }
 
-    for (uint32_t g0 = 0; g0 < nframes; g0 += Context::GROUP) {
-        uint32_t n = nframes - g0 < (uint32_t)Context::GROUP ? nframes - g0 : (uint32_t)Context::GROUP;
+    // folding launches may take 64 frames (a wave = ONE pixel x 64 frames): half as many launch boundaries
+    const uint32_t group = fold_batch ? (uint32_t)g.opt_group_frames : (uint32_t)Context::GROUP;
+    for (uint32_t g0 = 0; g0 < nframes; g0 += group) {
+        uint32_t n = nframes - g0 < group ? nframes - g0 : group;
         bool last = g0 + n >= nframes;
         if (fold_batch && n >= FOLD_MIN) {
             if (trace_fold(rp->frameNo + g0, n, want_img && last)) return g.err_code;
@@ -1129,6 +1131,9 @@ int svr_set_option(int key, int value)
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_BOUND_CULL: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_bound_cull = value; return 0;
     case SVR_OPT_FOLD: g.opt_fold = value ? 1 : 0; return 0;
+    case SVR_OPT_GROUP_FRAMES:
+        if (value != 8 && value != 16 && value != 32 && value != 64) return fail(-6, "SVR_OPT_GROUP_FRAMES: bad value %d (8, 16, 32, 64)", value);
+        g.opt_group_frames = value; return 0;
     case SVR_OPT_ROW_ORDER: g.opt_row_order = value ? 1 : 0; return 0;
     case SVR_OPT_FINE_MASK:
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_FINE_MASK: bad value %d (0 off, 1 auto, 2 always)", value);
@@ -1176,6 +1181,7 @@ int svr_get_option(int key)
     case SVR_OPT_RAY_SKIP: return g.opt_ray_skip;
     case SVR_OPT_BOUND_CULL: return g.opt_bound_cull;
     case SVR_OPT_FOLD: return g.opt_fold;
+    case SVR_OPT_GROUP_FRAMES: return g.opt_group_frames;
     case SVR_OPT_ROW_ORDER: return g.opt_row_order;
     case SVR_OPT_FINE_MASK: return g.opt_fine_mask;
     case SVR_OPT_FAST_MATH: return g.opt_fast_math;

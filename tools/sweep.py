@@ -12,7 +12,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from sunvolumerender_amd import abi, host, scenes  # noqa: E402
 
 KEYS = {"park_min": abi.OPT_PARK_MIN, "bound_cull": abi.OPT_BOUND_CULL, "empty_skip": abi.OPT_EMPTY_SKIP, "ray_skip": abi.OPT_RAY_SKIP,
-        "fl2": abi.OPT_FRAMES_PER_WAVE_LOG2, "kernel": abi.OPT_KERNEL, "frame_ahead": abi.OPT_FRAME_AHEAD, "fast_math": abi.OPT_FAST_MATH, "fold": abi.OPT_FOLD, "queue": abi.OPT_QUEUE, "park_end": abi.OPT_PARK_END, "fine_mask": abi.OPT_FINE_MASK, "row_order": abi.OPT_ROW_ORDER}
+        "fl2": abi.OPT_FRAMES_PER_WAVE_LOG2, "kernel": abi.OPT_KERNEL, "frame_ahead": abi.OPT_FRAME_AHEAD, "fast_math": abi.OPT_FAST_MATH, "fold": abi.OPT_FOLD, "queue": abi.OPT_QUEUE, "park_end": abi.OPT_PARK_END, "fine_mask": abi.OPT_FINE_MASK, "row_order": abi.OPT_ROW_ORDER, "group": abi.OPT_GROUP_FRAMES}
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="c3")
 ap.add_argument("--depth", type=int, default=1)
@@ -21,6 +21,7 @@ ap.add_argument("--spp", type=int, default=32)
 ap.add_argument("--count", action="store_true")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--layout", type=int, default=0)
+ap.add_argument("--shard", default="", help="strip_rows,rank,world")
 ap.add_argument("settings", nargs="*", default=[""])
 a = ap.parse_args()
 
@@ -29,6 +30,8 @@ dev = host.Device(0, fatal_errors=False)
 defaults = {k: dev.lib.svr_get_option(v) for k, v in KEYS.items()}
 c = host.Canvas(dev, sc.width, sc.height)
 scenes.apply_to_canvas(sc, c, a.layout)
+if a.shard:
+    dev.check(dev.lib.svr_set_row_shard(*[int(v) for v in a.shard.split(',')]))
 print(f"# {a.scene} depth {a.depth}, {a.frames} frames per measurement, {a.spp} per call | {dev.info()}", flush=True)
 
 
