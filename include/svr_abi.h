@@ -202,7 +202,6 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
                                      majorant-bound fetch culling -- a Woodcock iteration draws its accept number first and
                                      fetches only if it is below (largest alpha reachable in the macro-cell) / sigma_max; bit-identical
                                      results, same random-number stream (csrc/svr_accel.hip, k_bound_class) */
-#define SVR_OPT_PARK_MIN 16         /* reserved (experiments with parked fetches, csrc/svr_walk.hpp walk_run_parked); 1..64 */
 #define SVR_OPT_PARK_END 19         /* lane machine of the tile kernel (csrc/svr_lanes.hpp): shading / end-of-walk processing runs when this many
                                      lanes of the wave wait for it (or none can walk); 1..64, default 24.  Speed only */
 #define SVR_OPT_QUEUE 18            /* the tile kernel queues a path at its first scatter event and continues it on a per-lane state machine that

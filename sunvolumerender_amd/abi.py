@@ -137,7 +137,6 @@ OPT_RAYCAST_LANES_LOG2 = 12
 OPT_FRAME_AHEAD = 13
 OPT_FAST_MATH = 14
 OPT_BOUND_CULL = 15
-OPT_PARK_MIN = 16
 OPT_FOLD = 17
 OPT_QUEUE = 18
 OPT_PARK_END = 19

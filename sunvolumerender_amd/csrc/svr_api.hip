@@ -119,7 +119,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_min = 1, opt_park_end = 24, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 24, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -475,7 +475,6 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
     s.fine_mask = (tv->mm_fine && g.d_fine_mask && (g.opt_fine_mask == 2 || (g.opt_fine_mask == 1 && tv->mc_shift >= 4))) ? g.d_fine_mask : nullptr;
     s.fg_x = tv->fg_x; s.fg_y = tv->fg_y; s.fg_z = tv->fg_z; s.fg_xy = tv->fg_x * tv->fg_y;
     s.bound_cull = (g.opt_bound_cull == 2 || (g.opt_bound_cull == 1 && g.mask_cull_useful)) ? 1u : 0u;
-    s.park_min = (uint32_t)g.opt_park_min;
     s.park_end = (uint32_t)g.opt_park_end;
     return 0;
 }
@@ -1145,9 +1144,6 @@ int svr_set_option(int key, int value)
     case SVR_OPT_PARK_END:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_END: bad value %d (1..64)", value);
         g.opt_park_end = value; return 0;
-    case SVR_OPT_PARK_MIN:
-        if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_MIN: bad value %d (1..64)", value);
-        g.opt_park_min = value; return 0;
 #ifdef SVR_TEST_HOOKS
     // experiment builds only (tools/exp.py; `SVR_EXTRA_HIPCC_FLAGS=-DSVR_TEST_HOOKS python -m sunvolumerender_amd._build --force`)
     case 100: g.opt_debug_stop = value; return 0;      // timing ablation: stop every path after a phase (wrong images)
@@ -1187,7 +1183,6 @@ int svr_get_option(int key)
     case SVR_OPT_FAST_MATH: return g.opt_fast_math;
     case SVR_OPT_QUEUE: return g.opt_queue;
     case SVR_OPT_PARK_END: return g.opt_park_end;
-    case SVR_OPT_PARK_MIN: return g.opt_park_min;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     case SVR_OPT_FRAMES_PER_WAVE_LOG2: return g.opt_frames_log2;
     case SVR_OPT_RAYCAST_LANES_LOG2: return g.opt_rc_lanes;

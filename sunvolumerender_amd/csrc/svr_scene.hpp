@@ -49,7 +49,6 @@ struct DevScene {
     const uint32_t* fine_mask;     // `empty` bits of the fine level (cells of 2^(mc_shift-1)), global memory; null = not used
     int32_t fg_x, fg_y, fg_z, fg_xy;   // its grid and slice stride (cells)
     uint32_t bound_cull;           // 1: the bound-class table behind the masks is valid (majorant-bound fetch culling)
-    uint32_t park_min;             // lane machine: lanes waiting for a fetch / a re-march before the wave serves them
     uint32_t park_end;             // lane machine: lanes waiting for shading / a walk's end / a new record before the wave serves them
     float mc_scale[3];             // macro-grid coordinate = (p - vmin) * mc_scale + mc_off
     float mc_off;

@@ -485,99 +485,6 @@ SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rn
     }
 }
 
-// The walk loop.  Every iteration of the reference (woodcock_tracking.h:32-45) is: distance draw + log + advance, the
-// exit test, one fetch, the accept draw + test.  Here a lane's iteration is one of
-//   * FREE    t < t_occ (before the first possibly-occupied macro-cell, whole-ray march): no cell test, no fetch;
-//   * EMPTY   the trilinear cell lies in an `empty` macro-cell: sigma_t = 0, the accept test cannot pass;
-//   * CULLED  the accept draw is not below the cell's bound (majorant-bound culling, svr_accel.hip): cannot pass;
-//   * FETCH   everything else: 8 voxels, filter, LUT.
-// The first three cost ~50 vector instructions and no memory access; FETCH costs ~150 and eight gathers, and a wave
-// pays for it whenever ONE of its lanes needs it.  So lanes that need a fetch PARK: they stop iterating, keep their
-// accept draw, and the wave serves them together once s.park_min lanes wait (or nobody else can run); the same
-// for the wave-synchronous re-march of lanes that have left an occupied stretch (REMARCH: two consecutive
-// iterations in deep-empty cells; the march says where the next possibly-occupied cell is, or that the walk is
-// over if no draw follows it).  All of it is scheduling: each lane executes the reference's iterations in the
-// reference's order and consumes the reference's random numbers.  COUNT builds run every iteration (a walk a
-// production build would have ended keeps going) so that the iteration / tap counters stay the reference's.
-// MAP: the walk belongs to a pixel group with a GroupMap (primary walks of frame-major launches): an iteration in
-// an empty cell asks the map for the next possibly-occupied stretch and goes back to FREE iterations until then.
-template <int LAYOUT, bool COUNT, bool SKIP, bool REMARCH, bool MAP, typename LDS>
-SVR_DEV float walk_run_parked(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float tMin, float tMax, float t_occ,
-                              float& val, bool rng_live, Cnt& c, const GroupMap* map = nullptr, uint32_t P2 = 0u)
-{
-    enum : uint32_t { RUN = 0u, NEED_FETCH = 1u, NEED_MARCH = 2u, DONE = 3u };
-    const float INF = u2f(SVR_INF_BITS);
-    float t = tMin, result = -SVR_FLT_MAX, xi = 0.f;
-    const bool ray_skippable = SKIP && s.ray_skip && !rng_live && t_occ == INF;
-    if (COUNT && ray_skippable) c.wskip++;
-    bool tail_counted = false;          // COUNT builds only: a production build would have ended the walk
-    uint32_t st = RUN, clear_run = 0u, guard = 0u;
-    const uint32_t park_min = s.park_min;
-    for (;;) {
-        // ---- cheap phase: FREE / EMPTY / CULLED iterations; lanes drop out as they finish or need service ----
-        for (;;) {
-            if (st == RUN) {
-                if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; }
-                t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-                if (t > tMax || guard++ >= SVR_WALK_GUARD) st = DONE;
-                else {
-                    if (COUNT) c.taps++;
-                    if (SKIP && t < t_occ) {
-                        if (COUNT && !(ray_skippable || tail_counted)) c.ipre++;
-                        rng_skip(rng);                                  // the accept draw of a FREE iteration
-                    } else {
-                        const Cell cell = cell_of(s, orig + dir * t);
-                        CellInfo ci;
-                        ci.empty = false; ci.deep = false; ci.thr = INF;
-                        if (SKIP) ci = cell_info<REMARCH && !MAP>(L, s, cell);
-                        if (ci.empty) {
-                            rng_skip(rng);                              // sigma_t = 0: the draw is consumed, the test fails
-                            if (MAP) {
-                                if (map->valid) {
-                                    t_occ = group_map_next(*map, P2, t);      // <= t while the walk is in or next to an occupied stretch
-                                    if (t_occ == INF && !rng_live) {
-                                        if (!COUNT) st = DONE;                // nothing ahead and no draw follows the walk
-                                        else if (!tail_counted) { tail_counted = true; c.wskip++; }
-                                    }
-                                }
-                            } else if (REMARCH) {
-                                clear_run = ci.deep ? clear_run + 1u : 0u;
-                                if (clear_run == 2u) st = NEED_MARCH;
-                            }
-                        } else {
-                            clear_run = 0u;
-                            xi = rng_uniform(rng);
-                            if (xi < ci.thr) st = NEED_FETCH;          // else CULLED: xi >= bound >= sigma_t * invSigmaMax
-                            else if (COUNT) c.cull++;
-                        }
-                    }
-                }
-            }
-            const uint64_t running = __ballot(st == RUN);
-            if (running == 0ull) break;
-            if ((uint32_t)__popcll(__ballot(st == NEED_FETCH || st == NEED_MARCH)) >= park_min) break;
-        }
-        // ---- service phase ----
-        if (st == NEED_FETCH) {
-            if (COUNT) c.exec++;
-            val = tex_fetch<LAYOUT>(s, cell_of(s, orig + dir * t)) * s.densityScale;
-            const float sigma_t = alpha_of(L, s, val);
-            if (xi < sigma_t * s.invSigmaMax) { st = DONE; result = t; }
-            else st = RUN;
-        } else if (SKIP && REMARCH && !MAP && st == NEED_MARCH) {
-            t_occ = first_occupied(s, L, orig, dir, t, tMax);
-            clear_run = 0u;
-            st = RUN;
-            if (t_occ == INF && !rng_live) {
-                if (!COUNT) st = DONE;
-                else if (!tail_counted) { tail_counted = true; c.wskip++; }
-            }
-        }
-        if (__ballot(st != DONE) == 0ull) break;
-    }
-    return result;
-}
-
 // sample_distance in one piece (tile kernel)
 template <int LAYOUT, bool COUNT, bool SKIP, bool REMARCH, typename LDS>
 SVR_DEV float walk(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float& tMin, float& tMax,

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Timing sweep over library options on one scene (one process, one canvas).
 usage: tools/sweep.py [--scene c3] [--depth 1] [--frames 64] [--spp 32] [--count] setting...
-       setting = comma-separated name=value pairs; names: park_min bound_cull empty_skip ray_skip fl2 kernel frame_ahead fast_math
-       e.g.  tools/sweep.py --scene c3n park_min=1 park_min=8 park_min=16,bound_cull=0"""
+       setting = comma-separated name=value pairs; names: see KEYS below
+       e.g.  tools/sweep.py --scene c3n defaults bound_cull=0 queue=2,park_end=16"""
 import argparse
 import sys
 import time
@@ -11,7 +11,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from sunvolumerender_amd import abi, host, scenes  # noqa: E402
 
-KEYS = {"park_min": abi.OPT_PARK_MIN, "bound_cull": abi.OPT_BOUND_CULL, "empty_skip": abi.OPT_EMPTY_SKIP, "ray_skip": abi.OPT_RAY_SKIP,
+KEYS = {"bound_cull": abi.OPT_BOUND_CULL, "empty_skip": abi.OPT_EMPTY_SKIP, "ray_skip": abi.OPT_RAY_SKIP,
         "fl2": abi.OPT_FRAMES_PER_WAVE_LOG2, "kernel": abi.OPT_KERNEL, "frame_ahead": abi.OPT_FRAME_AHEAD, "fast_math": abi.OPT_FAST_MATH, "fold": abi.OPT_FOLD, "queue": abi.OPT_QUEUE, "park_end": abi.OPT_PARK_END, "fine_mask": abi.OPT_FINE_MASK, "row_order": abi.OPT_ROW_ORDER, "group": abi.OPT_GROUP_FRAMES}
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="c3")
