@@ -499,8 +499,8 @@ int ensure_slots(uint32_t W, uint32_t H, uint32_t nslots)
 
 // per-wave scatter-record queues (REC_WORDS x QUEUE_CAP words) and pending-radiance rows (QUEUE_TASKS x 3 x 64 floats) of the
 // tile kernel's QUEUE builds (svr_trace_tile.hip, svr_lanes.hpp): 57 KB + 24 KB per wave, 330 MB for 256 blocks
-constexpr size_t QUEUE_WORDS_PER_BLOCK = (size_t)14 * 1024 * 16;
-constexpr size_t PEND_FLOATS_PER_BLOCK = (size_t)32 * 3 * 64 * 16;
+using svr::QUEUE_WORDS_PER_BLOCK;
+using svr::PEND_FLOATS_PER_BLOCK;
 int ensure_record_queues(uint32_t blocks)
 {
     if (g.d_queue && g.queue_blocks >= blocks) return 0;

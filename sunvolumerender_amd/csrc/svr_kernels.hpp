@@ -13,6 +13,14 @@ constexpr uint32_t TICKET_STRIDE = 32;      // in uint32 words
 constexpr uint32_t MASK_WORDS_MAX = 8192;   // words of the LDS-resident `empty` bitmask (32 KiB): up to 64^3 macro-cells
 constexpr uint32_t DIST_WORDS_MAX = 4096;   // words of the half-resolution 4-bit distance field (16 KiB): up to 32^3 coarse cells
 constexpr int DIST_CAP = 15;
+// QUEUE builds of the tile kernel (svr_trace_tile.hip, svr_lanes.hpp): per wave, up to QUEUE_CAP scatter records of REC_WORDS
+// words and the radiance of QUEUE_TASKS tasks (3 channels x 64 lanes), in global memory; TILE_WAVES waves per block
+constexpr uint32_t REC_WORDS = 14;      // pt(3) wo(3) val rng(6) id
+constexpr uint32_t QUEUE_TASKS = 32;
+constexpr uint32_t QUEUE_CAP = 1024;
+constexpr uint32_t TILE_WAVES = 16;
+constexpr size_t QUEUE_WORDS_PER_BLOCK = (size_t)REC_WORDS * QUEUE_CAP * TILE_WAVES;
+constexpr size_t PEND_FLOATS_PER_BLOCK = (size_t)QUEUE_TASKS * 3 * 64 * TILE_WAVES;
 // Bound classes (svr_accel.hip, k_bound_class): 4 bits per half-resolution macro-cell = smallest class c whose threshold
 // BOUND_THR(c) is >= (largest transfer-function alpha any fetch in the cell can return) x invSigmaMax.
 constexpr uint32_t BOUND_CLASSES = 16;

@@ -25,7 +25,6 @@
 
 namespace svr {
 
-constexpr uint32_t REC_WORDS = 14;      // pt(3) wo(3) val rng(6) id
 
 // Phase profile of experiment builds (-DSVR_TEST_HOOKS): per phase, shader cycles the waves spent in it and the same
 // weighted by the lanes that had work there (-> lane utilisation per phase); read with svr_debug_phase_profile.

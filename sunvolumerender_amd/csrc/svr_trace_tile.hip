@@ -208,9 +208,8 @@ constexpr uint32_t PEND_TASKS = 4;
 constexpr uint32_t PEND_ROW = 65;
 // QUEUE builds keep the radiance of the last QUEUE_TASKS tasks in a per-wave buffer in global memory instead (rows of 64
 // floats; written and read back by the same CU, so it lives in L2), and up to QUEUE_CAP scatter records per wave
-constexpr uint32_t QUEUE_TASKS = 32;
-constexpr uint32_t QUEUE_CAP = 1024;
-constexpr uint32_t TILE_WAVES = SVR_TILE_THREADS / 64;
+// (QUEUE_TASKS = 32 and QUEUE_CAP = 1024: svr_kernels.hpp, shared with the allocation in svr_api.hip)
+static_assert(TILE_WAVES == SVR_TILE_THREADS / 64, "svr_kernels.hpp sizes the queues for 16 waves per block");
 struct LdsPend {
     float L[TILE_WAVES][PEND_TASKS * 3][PEND_ROW];
     uint32_t task[TILE_WAVES][PEND_TASKS];

@@ -275,6 +275,11 @@ class Canvas:
         nz, ny, nx = vox.shape
         h = self.lib.svr_create_volume_texture(vox.ctypes.data_as(C.c_void_p), nx, ny, nz, 0, int(layout))
         self.dev.check()
+        old = getattr(self, "_volume_tex", 0)
+        if old and old in self._textures:                      # a second LoadVolume replaces the texture: free the old one now
+            self._textures.remove(old)
+            self.lib.svr_destroy_texture(old)
+        self._volume_tex = h
         self._textures.append(h)
         gf = self.deviceVolume.gradientFactor
         self.deviceVolume = create_device_volume(h, (nx, ny, nz), spacing, max_magnitude)
@@ -340,8 +345,13 @@ class Canvas:
         t = np.ascontiguousarray(rgba, dtype=np.float32).reshape(-1, 4)
         h = self.lib.svr_create_tf_texture(t.ctypes.data_as(C.c_void_p), t.shape[0], 0)
         self.dev.check()
+        old = getattr(self, "_tf_tex", 0)
+        self._tf_tex = h
         self._textures.append(h)
         self.SetTransferFunction(h, maxOpacity)
+        if old and old in self._textures:                      # replaced: free the previous table
+            self._textures.remove(old)
+            self.lib.svr_destroy_texture(old)
 
     def SetTransferFunction(self, tex: int, maxOpacity: float):
         self.transferFunction.tex = int(tex)
