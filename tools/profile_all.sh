@@ -10,5 +10,5 @@ for spec in "c3_d1:--scene c3" "c3_d1_noskip:--scene c3 --empty-skip 0" "c3n_d1:
   tag=${spec%%:*}; args=${spec#*:}
   echo "=== $tag ($args)"
   PROF_STEPS=${PROF_STEPS:-1} bash tools/profile.sh ${R}_$tag $args --spp-per-step ${PROF_SPP:-64} > gpurun_out/prof_${R}_$tag.log 2>&1 || { echo "profile $tag failed"; tail -5 gpurun_out/prof_${R}_$tag.log; exit 1; }
-  python3 tools/pmc_json.py gpurun_out/prof_${R}_$tag/summary.txt "k_trace_tile" $tag gpurun_out/prof_${R}_$tag/pmc.json "bench.py $args --spp-per-step ${PROF_SPP:-64} (32 frames per launch)" | cut -c1-400
+  python3 tools/pmc_json.py gpurun_out/prof_${R}_$tag/summary.txt "k_trace_tile" $tag gpurun_out/prof_${R}_$tag/pmc.json "bench.py $args --spp-per-step ${PROF_SPP:-64} (64 frames per launch)" | cut -c1-400
 done
