@@ -78,6 +78,39 @@ def test_render_window(hip_dev):
     assert not part[mask].any() and c["paths"] == 40 * 41
 
 
+def test_frame_zero_clears_the_whole_accumulator_under_a_window_or_shard(hip_dev):
+    """clear_hdr_buffer (pathtracer.cu:86-94) zeroes the WHOLE accumulator at frame 0; under a window or a row shard the kernels
+    touch only their own pixels, so the library clears the rest: a caller-supplied buffer with stale values must come out zero
+    outside the owned pixels (the ranks' strips are summed into one frame afterwards)."""
+    sc = scenes.make_scene("tiny_head")
+    for kw in (dict(window=(10, 20, 50, 61)), dict(shard=(8, 1, 3))):
+        canvas = host.Canvas(hip_dev, sc.width, sc.height)
+        try:
+            scenes.apply_to_canvas(sc, canvas)
+            hip_dev.to_device(int(canvas.renderParams.hdrBuffer), np.full((sc.height, sc.width, 3), 7.5, dtype=np.float32))
+            if "window" in kw:
+                hip_dev.check(hip_dev.lib.svr_set_render_window(*kw["window"]))
+                owned = np.zeros((sc.height, sc.width), bool)
+                x0, y0, x1, y1 = kw["window"]
+                owned[y0:y1, x0:x1] = True
+            else:
+                hip_dev.check(hip_dev.lib.svr_set_row_shard(*kw["shard"]))
+                owned = np.zeros((sc.height, sc.width), bool)
+                owned[dist.owned_rows(sc.height, *kw["shard"])] = True
+            for batch in (False, True):
+                canvas.ReStartRender()
+                canvas.paint_frames(16) if batch else canvas.paint()
+                hip_dev.synchronize()
+                hdr = canvas.read_hdr()
+                assert not hdr[~owned].any(), f"stale values outside the owned pixels ({kw}, batch={batch})"
+                assert hdr[owned].any()
+                hip_dev.to_device(int(canvas.renderParams.hdrBuffer), np.full((sc.height, sc.width, 3), 7.5, dtype=np.float32))
+        finally:
+            hip_dev.lib.svr_set_render_window(0, 0, -1, -1)
+            hip_dev.lib.svr_set_row_shard(0, 0, 1)
+            canvas.close()
+
+
 def test_canvas_edits_restart_and_match_oracle(hip_dev):
     """Setter -> setup_* -> frameNo = 0 (gui/canvas.h:43-175): density scale, clip planes, lights, exposure."""
     base = scenes.make_scene("tiny_head", trace_depth=2)
