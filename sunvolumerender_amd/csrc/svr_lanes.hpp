@@ -135,177 +135,215 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
         }
     };
 
-    // Scheduling (phase profiles of experiment builds, c3 at traceDepth 4): the services SHADE and END cost ~10^3
-    // instructions each, the same for 1 lane or 64.  Serving as soon as 16 lanes wait ran them at 30-40 % lane utilisation
-    // and 65 % of the drain's time; serving only when NO lane can walk (strict generations) ran them at 90-99 % but left the
-    // wave waiting for its few longest walks (51 % of the time at 7 walking lanes).  So: a service runs when park_end lanes
-    // wait for it, or when nobody walks.
+    // the services of a walking lane that cannot wait: the fetch an iteration asked for, the re-march after an occupied stretch
+    auto serve_fetch_march = [&](bool mine) {
+        // FETCH: 8 voxels + filter + LUT, then the accept test with the draw the lane kept
+        if (__ballot(mine && st == FETCH) != 0ull) {
+            if (mine && st == FETCH) {
+                if (COUNT) c.exec++;
+                val = tex_fetch<LAYOUT>(s, cell_of(s, orig + dir * t)) * s.densityScale;
+                const float sigma_t = alpha_of(L_, s, val);
+                if (xi < sigma_t * s.invSigmaMax) { st = END; hit = true; }
+                else st = WALK;
+            }
+        }
+        // MARCH: the walk has left an occupied stretch: where is the next one?
+        if (SKIP && __ballot(mine && st == MARCH) != 0ull) {
+            if (mine && st == MARCH) {
+                t_occ = first_occupied(s, L_, orig, dir, t, tMax);
+                clear_run = 0u;
+                st = WALK;
+                if (t_occ == INF && !rng_live) {
+                    if (!COUNT) st = END;                               // nothing ahead and no draw follows the walk: it ends without a collision
+                    else if (!tail_counted) { tail_counted = true; c.wskip++; }
+                }
+            }
+        }
+    };
+    // a finished path hands its radiance to its task's row
+    auto finish = [&]() {
+        float* o = pendL + (id >> 6) * 3u * pend_row + (id & 63u);
+        o[0] = L.x; o[pend_row] = L.y; o[2u * pend_row] = L.z;
+        st = IDLE;
+    };
+    // END of a CONTINUATION walk (pathtracer.cu:231-244): no collision -> the path is over; collision -> the next scatter point
+    auto end_continuation = [&]() {
+        if (!hit) {
+            if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+            finish();
+        } else {
+            vs.wo = -dir;
+            vs.pt = orig + dir * t;
+            st = SHADE;
+        }
+    };
+    // END of a SHADOW walk (pathtracer.cu:191-198, 258-276): transmittance -> direct light, then the next bounce's direction and walk
+    auto end_shadow = [&]() {
+        v3 Ld = V3(0.f, 0.f, 0.f);
+        if (have_light) {
+            // transmittance.h:15-16 on the walk's result ts (t, or -FLT_MAX), with the box interval of the shadow ray
+            const float ts = hit ? t : -SVR_FLT_MAX;
+            const float Tr = ((ts > tMin) && (ts < tMax)) ? 0.f : 1.f;
+            const float kf = Tr * (float)s.num_lights;
+            const DevLight& l = s.lights[lightId];
+            const v3 Li = V3(l.radiance[0], l.radiance[1], l.radiance[2]);     // sample_light returned true: cosTerm > 0
+            Ld = ((B * kf) * Li) / pdfL;
+        }
+        L = L + T * Ld;
+        if (k + 1u >= traceDepth) { finish(); return; }                 // sample_bsdf / roulette of the last bounce cannot reach L
+        v3 wi; float pdf = 0.f;
+        const v3 f = bsdf_sample(vs, wi, pdf, rng);
+        const float cosTerm = __builtin_fabsf(dot(normalize(vs.gradient), wi));
+        if (fmax_(f.x, fmax_(f.y, f.z)) > 0.f && pdf > 0.f) {
+            if (vs.st == 0) T = T * (f / (pdf * (1.f - vs.Pbrdf)));
+            else T = T * ((f * cosTerm) / (pdf * vs.Pbrdf));
+        }
+        orig = vs.pt;
+        dir = wi;
+        if (k >= 3u && russian_roulette(T, rng)) { finish(); return; }
+        ++k;
+        begin_walk(false, false);                                       // the next bounce's walk (pathtracer.cu:218)
+        if (st == END) {                                                // its result is known: no collision
+            if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+            finish();
+        }
+    };
+    // SHADE: VolumeSample + next-event estimation up to the shadow walk (pathtracer.cu:237-257, 171-191)
+    auto shade = [&]() {
+        if (COUNT) { c.scatter++; c.taps += 7; c.exec += 6; }
+        tf_rgba(s, s.tf, val, vs.color);
+        {
+            // Gradient_CentralDiff, cuda_volume.h:54-61
+            const v3 q = vs.pt;
+            float xd = intensity_at<LAYOUT>(s, V3(q.x + s.spacing[0], q.y + 0.f, q.z + 0.f)) -
+                       intensity_at<LAYOUT>(s, V3(q.x - s.spacing[0], q.y - 0.f, q.z - 0.f));
+            float yd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + s.spacing[1], q.z + 0.f)) -
+                       intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - s.spacing[1], q.z - 0.f));
+            float zd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + 0.f, q.z + s.spacing[2])) -
+                       intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - 0.f, q.z - s.spacing[2]));
+            vs.gradient = V3((xd * 0.5f) * s.invSpacing[0], (yd * 0.5f) * s.invSpacing[1], (zd * 0.5f) * s.invSpacing[2]);
+        }
+        const float gradMag = __builtin_sqrtf(dot(vs.gradient, vs.gradient));
+        vs.Pbrdf = vs.color[3] * (1.f - expf_(s.pbrdf_c * gradMag * 65535.f * s.invMaxMagnitude));
+        vs.st = (rng_uniform(rng) < vs.Pbrdf) ? 1 : 0;
+        // estimate_direct_light, pathtracer.cu:171-198
+        have_light = false;
+        orig = vs.pt;
+        st = END; shadow = true; hit = false;
+        if (s.num_lights != 0) {
+            int li = (int)((float)s.num_lights * rng_uniform(rng));
+            li = li < (int)s.num_lights ? li : (int)s.num_lights - 1;
+            v3 wiL, Li;
+            if (sample_light(s.lights[li], vs.pt, rng, wiL, pdfL, Li)) {
+                have_light = true;
+                lightId = (uint32_t)li;
+                B = bsdf_eval(vs, wiL);
+                if (COUNT) c.shadow++;
+                dir = wiL;
+                // the draws of sample_bsdf / roulette follow the shadow walk unless this is the last bounce
+                begin_walk(true, k + 1u < traceDepth);
+            }
+        }
+    };
+
+    // refill the idle lanes from the queue: a popped record is a path at its first scatter point
+    auto refill = [&]() {
+        const uint64_t idle = __ballot(st == IDLE);
+        if (idle == 0ull || next >= count) return;
+        PROF_BEGIN(pr, PH_REFILL);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        const uint32_t i = next + lane_rank(idle);
+        if (st == IDLE && i < count) {
+            const uint32_t* p = Q.q + i;
+            const uint32_t cap = Q.cap;
+            vs.pt = V3(u2f(p[0]), u2f(p[cap]), u2f(p[2 * cap]));
+            vs.wo = V3(u2f(p[3 * cap]), u2f(p[4 * cap]), u2f(p[5 * cap]));
+            val = u2f(p[6 * cap]);
+            rng.v0 = p[7 * cap]; rng.v1 = p[8 * cap]; rng.v2 = p[9 * cap]; rng.v3 = p[10 * cap]; rng.v4 = p[11 * cap]; rng.d = p[12 * cap];
+            id = p[13 * cap];
+            L = V3(0.f, 0.f, 0.f); T = V3(1.f, 1.f, 1.f); k = 0u;
+            st = SHADE;
+        }
+        PROF_END(pr, min(n_idle, count - next));
+        next = min(count, next + n_idle);
+    };
+
+    // Scheduling (phase profiles of experiment builds, c3 at traceDepth 4): the services (END: end of a shadow walk + BSDF
+    // sampling + next walk's set-up; SHADE) cost ~10^3 instructions each, the same for 1 lane or 64.  Serving as soon as 16
+    // lanes waited ran them at 30-40 % lane utilisation and 65 % of the drain's time; serving only when NO lane can walk
+    // (strict generations) ran them at 90-99 % but left the wave waiting for its few longest walks (51 % of the time at 7
+    // walking lanes).  So a service runs when park_end lanes wait for it, or when nobody walks.
     const uint32_t park_end = s.park_end;
-    for (;;) {
-        // ---- WALK: iterations of every walking lane, fetches and re-marches served as they come, until every walk is over ----
-        PROF_BEGIN(pw, PH_CHEAP);
-#if SVR_PROF
-        uint32_t pc_it = 0u, pc_walk = 0u;
-#endif
-        while (__ballot(st == WALK) != 0ull) {
-            if ((uint32_t)__popcll(__ballot(st == END)) >= park_end) break;
-            if ((uint32_t)__popcll(__ballot(st == SHADE || (st == IDLE && next < count))) >= park_end) break;
-#if SVR_PROF
-            pc_it++; pc_walk += (uint32_t)__popcll(__ballot(st == WALK));
-#endif
-            if (st == WALK) iterate();
-            // FETCH: 8 voxels + filter + LUT, then the accept test with the draw the lane kept
-            if (__ballot(st == FETCH) != 0ull) {
-                if (st == FETCH) {
-                    if (COUNT) c.exec++;
-                    val = tex_fetch<LAYOUT>(s, cell_of(s, orig + dir * t)) * s.densityScale;
-                    const float sigma_t = alpha_of(L_, s, val);
-                    if (xi < sigma_t * s.invSigmaMax) { st = END; hit = true; }
-                    else st = WALK;
-                }
+    if constexpr (DEPTH1) {
+        // traceDepth 1: a path is over when its shadow walk is, so ONE service takes every waiting lane through
+        // [end of walk -> radiance -> next record -> shading -> next shadow walk] (c3: 8032 against 7336 Msamples/s for two
+        // separately triggered services, 7763 for straight-line paths)
+        for (;;) {
+            PROF_BEGIN(pw, PH_CHEAP);
+            while (__ballot(st == WALK) != 0ull) {
+                if ((uint32_t)__popcll(__ballot(st == END || st == SHADE || (st == IDLE && next < count))) >= park_end) break;
+                if (st == WALK) iterate();
+                serve_fetch_march(true);
             }
-            // MARCH: the walk has left an occupied stretch: where is the next one?
-            if (SKIP && __ballot(st == MARCH) != 0ull) {
-                if (st == MARCH) {
-                    t_occ = first_occupied(s, L_, orig, dir, t, tMax);
-                    clear_run = 0u;
-                    st = WALK;
-                    if (t_occ == INF && !rng_live) {
-                        if (!COUNT) st = END;                           // nothing ahead and no draw follows the walk: it ends without a collision
-                        else if (!tail_counted) { tail_counted = true; c.wskip++; }
-                    }
-                }
-            }
-        }
-#if SVR_PROF
-        PROF_END(pw, pc_it ? pc_walk / pc_it : 0u);
-        if ((threadIdx.x & 63u) == 0u) { atomicAdd(&c_prof[2 * PH_N], (unsigned long long)pc_it); atomicAdd(&c_prof[2 * PH_N + 1], (unsigned long long)pc_walk); }
-#endif
-        const bool walking = __ballot(st == WALK) != 0ull;
-        // ---- END: walks that are over ----
-        {
-            const uint64_t m = __ballot(st == END);
-            if (m != 0ull && (!walking || (uint32_t)__popcll(m) >= park_end)) {
+            PROF_END(pw, 32u);
+            if (__ballot(st == END) != 0ull) {
                 PROF_BEGIN(pe, PH_END);
-                if (st == END) {
-                    bool finished = false;
-                    if (shadow) {
-                        v3 Ld = V3(0.f, 0.f, 0.f);
-                        if (have_light) {
-                            // transmittance.h:15-16 on the walk's result ts (t, or -FLT_MAX), with the box interval of the shadow ray
-                            const float ts = hit ? t : -SVR_FLT_MAX;
-                            const float Tr = ((ts > tMin) && (ts < tMax)) ? 0.f : 1.f;
-                            const float kf = Tr * (float)s.num_lights;
-                            const DevLight& l = s.lights[lightId];
-                            const v3 Li = V3(l.radiance[0], l.radiance[1], l.radiance[2]);     // sample_light returned true: cosTerm > 0
-                            Ld = ((B * kf) * Li) / pdfL;
-                        }
-                        L = L + T * Ld;
-                        if (k + 1u >= traceDepth) finished = true;     // sample_bsdf / roulette of the last bounce cannot reach L
-                        else {
-                            v3 wi; float pdf = 0.f;
-                            const v3 f = bsdf_sample(vs, wi, pdf, rng);
-                            const float cosTerm = __builtin_fabsf(dot(normalize(vs.gradient), wi));
-                            if (fmax_(f.x, fmax_(f.y, f.z)) > 0.f && pdf > 0.f) {
-                                if (vs.st == 0) T = T * (f / (pdf * (1.f - vs.Pbrdf)));
-                                else T = T * ((f * cosTerm) / (pdf * vs.Pbrdf));
-                            }
-                            orig = vs.pt;
-                            dir = wi;
-                            if (k >= 3u && russian_roulette(T, rng)) finished = true;
-                            else {
-                                ++k;
-                                begin_walk(false, false);              // the next bounce's walk (pathtracer.cu:218)
-                                if (st == END) {                        // its result is known: no collision
-                                    if (s.env_on_escape) L = L + T * env_radiance(s, dir);
-                                    finished = true;
-                                }
-                            }
-                        }
-                    } else if (!hit) {
-                        if (s.env_on_escape) L = L + T * env_radiance(s, dir);
-                        finished = true;
-                    } else {
-                        vs.wo = -dir;
-                        vs.pt = orig + dir * t;
-                        st = SHADE;
-                    }
-                    if (finished) {
-                        float* o = pendL + (id >> 6) * 3u * pend_row + (id & 63u);
-                        o[0] = L.x; o[pend_row] = L.y; o[2u * pend_row] = L.z;
-                        st = IDLE;
-                    }
-                }
-                PROF_END(pe, (uint32_t)__popcll(m));
-                if (__ballot(st == WALK) != 0ull) continue;            // the next bounce's walks first: their hits join the shading below
+                if (st == END) end_shadow();
+                PROF_END(pe, 32u);
             }
+            refill();
+            {
+                const uint64_t m = __ballot(st == SHADE);
+                if (m != 0ull) {
+                    PROF_BEGIN(ps, PH_SHADE);
+                    if (st == SHADE) shade();
+                    PROF_END(ps, (uint32_t)__popcll(m));
+                }
+            }
+            if (__ballot(st != IDLE) == 0ull) break;
         }
-        const bool shade_now = !walking || (uint32_t)__popcll(__ballot(st == SHADE || (st == IDLE && next < count))) >= park_end;
-        // ---- refill the idle lanes from the queue ----
-        if (next < count && shade_now) {
-            const uint64_t idle = __ballot(st == IDLE);
-            if (idle != 0ull) {
-                PROF_BEGIN(pr, PH_REFILL);
-                const uint32_t n_idle = (uint32_t)__popcll(idle);
-                const uint32_t i = next + lane_rank(idle);
-                if (st == IDLE && i < count) {
-                    const uint32_t* p = Q.q + i;
-                    const uint32_t cap = Q.cap;
-                    vs.pt = V3(u2f(p[0]), u2f(p[cap]), u2f(p[2 * cap]));
-                    vs.wo = V3(u2f(p[3 * cap]), u2f(p[4 * cap]), u2f(p[5 * cap]));
-                    val = u2f(p[6 * cap]);
-                    rng.v0 = p[7 * cap]; rng.v1 = p[8 * cap]; rng.v2 = p[9 * cap]; rng.v3 = p[10 * cap]; rng.v4 = p[11 * cap]; rng.d = p[12 * cap];
-                    id = p[13 * cap];
-                    L = V3(0.f, 0.f, 0.f); T = V3(1.f, 1.f, 1.f); k = 0u;
-                    st = SHADE;
-                }
-                PROF_END(pr, min(n_idle, count - next));
-                next = min(count, next + n_idle);
+    } else {
+        // deeper paths: the two services are triggered separately and the continuation walks (a few iterations inside the
+        // medium) run in the common walk loop -- taking the served lanes through [end -> continuation walk -> end -> shading]
+        // in one go with the walks in flight paused was slower (c3 depth 2 / 4: 2977 / 1996 against 3784 / 2491 Msamples/s)
+        for (;;) {
+            PROF_BEGIN(pw, PH_CHEAP);
+#if SVR_PROF
+            uint32_t pc_it = 0u, pc_walk = 0u;
+#endif
+            while (__ballot(st == WALK) != 0ull) {
+                if ((uint32_t)__popcll(__ballot(st == END)) >= park_end) break;
+                if ((uint32_t)__popcll(__ballot(st == SHADE || (st == IDLE && next < count))) >= park_end) break;
+#if SVR_PROF
+                pc_it++; pc_walk += (uint32_t)__popcll(__ballot(st == WALK));
+#endif
+                if (st == WALK) iterate();
+                serve_fetch_march(true);
             }
-        }
-        // ---- SHADE: VolumeSample + next-event estimation up to the shadow walk (pathtracer.cu:237-257, 171-191) ----
-        {
-            const uint64_t m = __ballot(st == SHADE);
-            if (m == 0ull && !walking && __ballot(st != IDLE) == 0ull) break;   // no walk, no end, no record, nothing to shade: the queue is drained
-            if (m == 0ull || !shade_now) continue;
-            PROF_BEGIN(ps, PH_SHADE);
-            if (st == SHADE) {
-                if (COUNT) { c.scatter++; c.taps += 7; c.exec += 6; }
-                tf_rgba(s, s.tf, val, vs.color);
-                {
-                    // Gradient_CentralDiff, cuda_volume.h:54-61
-                    const v3 q = vs.pt;
-                    float xd = intensity_at<LAYOUT>(s, V3(q.x + s.spacing[0], q.y + 0.f, q.z + 0.f)) -
-                               intensity_at<LAYOUT>(s, V3(q.x - s.spacing[0], q.y - 0.f, q.z - 0.f));
-                    float yd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + s.spacing[1], q.z + 0.f)) -
-                               intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - s.spacing[1], q.z - 0.f));
-                    float zd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + 0.f, q.z + s.spacing[2])) -
-                               intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - 0.f, q.z - s.spacing[2]));
-                    vs.gradient = V3((xd * 0.5f) * s.invSpacing[0], (yd * 0.5f) * s.invSpacing[1], (zd * 0.5f) * s.invSpacing[2]);
-                }
-                const float gradMag = __builtin_sqrtf(dot(vs.gradient, vs.gradient));
-                vs.Pbrdf = vs.color[3] * (1.f - expf_(s.pbrdf_c * gradMag * 65535.f * s.invMaxMagnitude));
-                vs.st = (rng_uniform(rng) < vs.Pbrdf) ? 1 : 0;
-                // estimate_direct_light, pathtracer.cu:171-198
-                have_light = false;
-                orig = vs.pt;
-                st = END; shadow = true; hit = false;
-                if (s.num_lights != 0) {
-                    int li = (int)((float)s.num_lights * rng_uniform(rng));
-                    li = li < (int)s.num_lights ? li : (int)s.num_lights - 1;
-                    v3 wiL, Li;
-                    if (sample_light(s.lights[li], vs.pt, rng, wiL, pdfL, Li)) {
-                        have_light = true;
-                        lightId = (uint32_t)li;
-                        B = bsdf_eval(vs, wiL);
-                        if (COUNT) c.shadow++;
-                        dir = wiL;
-                        // the draws of sample_bsdf / roulette follow the shadow walk unless this is the last bounce
-                        begin_walk(true, k + 1u < traceDepth);
-                    }
+#if SVR_PROF
+            PROF_END(pw, pc_it ? pc_walk / pc_it : 0u);
+            if ((threadIdx.x & 63u) == 0u) { atomicAdd(&c_prof[2 * PH_N], (unsigned long long)pc_it); atomicAdd(&c_prof[2 * PH_N + 1], (unsigned long long)pc_walk); }
+#endif
+            const bool walking = __ballot(st == WALK) != 0ull;
+            {
+                const uint64_t m = __ballot(st == END);
+                if (m != 0ull && (!walking || (uint32_t)__popcll(m) >= park_end)) {
+                    PROF_BEGIN(pe, PH_END);
+                    if (st == END) { if (shadow) end_shadow(); else end_continuation(); }
+                    PROF_END(pe, (uint32_t)__popcll(m));
+                    if (__ballot(st == WALK) != 0ull) continue;        // the next bounce's walks first: their hits join the shading below
                 }
             }
-            PROF_END(ps, (uint32_t)__popcll(m));
+            const bool shade_now = !walking || (uint32_t)__popcll(__ballot(st == SHADE || (st == IDLE && next < count))) >= park_end;
+            if (shade_now) refill();
+            {
+                const uint64_t m = __ballot(st == SHADE);
+                if (m == 0ull && !walking && __ballot(st != IDLE) == 0ull) break;   // no walk, no end, no record, nothing to shade: the queue is drained
+                if (m == 0ull || !shade_now) continue;
+                PROF_BEGIN(ps, PH_SHADE);
+                if (st == SHADE) shade();
+                PROF_END(ps, (uint32_t)__popcll(m));
+            }
         }
     }
 }
