@@ -542,6 +542,53 @@ def test_degenerate_scenes(hip_dev, case):
             canvas.close()
 
 
+@pytest.mark.parametrize("case", ["tf_opaque", "dense_scale", "voxel_1", "image_2x2", "noisy", "odd", "window", "shard"])
+def test_queue_machine_corner_cases(hip_dev, case):
+    """The scatter-record queue + per-lane state machine (SVR_OPT_QUEUE = 2: forced on) where it is stressed: every path
+    scatters (opaque table: the queue fills and is drained before the 32 tasks are through), saturated table, one-voxel volume,
+    2x2 image (almost every lane of a task is dead), unskippable medium, a non-cubic thin-lens scene, a window and a row shard --
+    at traceDepth 1 (merged service), 3 and 6 (separate services, roulette), launches of 40 frames (24 idle frame lanes), of
+    64 + 3 and of 9; production and counting builds against the oracle."""
+    base = scenes.make_scene("tiny_head")
+    sc, kw = base, {}
+    if case == "tf_opaque":
+        tf = base.tf_rgba.copy(); tf[:, 3] = 1.0
+        sc = dataclasses.replace(base, tf_rgba=tf, max_opacity=1.0)
+    elif case == "dense_scale":
+        sc = dataclasses.replace(base, density_scale=37.5)
+    elif case == "voxel_1":
+        sc = dataclasses.replace(base, vox=np.full((1, 1, 1), 40000, dtype=np.uint16), max_magnitude=100.0,
+                                 lights=[host.place_area_light(20.0, 30.0, 12.0, 3.0, (1, 1, 1), 300.0)])
+    elif case == "image_2x2":
+        sc = dataclasses.replace(base, width=2, height=2)
+    elif case == "noisy":
+        sc = scenes.make_scene("tiny_head_noisy")
+    elif case == "odd":
+        sc = _odd_scene(depth=1)
+    elif case == "window":
+        kw = dict(window=(10, 20, 50, 61))
+    elif case == "shard":
+        kw = dict(shard=(8, 1, 3))
+    hip_dev.set_option(abi.OPT_QUEUE, 2)
+    try:
+        for depth, frames in ((1, 40), (3, 67), (6, 9)):
+            sd = dataclasses.replace(sc, trace_depth=depth)
+            ref_hdr, _, ref_c = oracle_frames(sd, frames)
+            hdr, _, c = hip_frames(hip_dev, sd, frames, batch=True, **kw)
+            if "window" in kw:
+                x0, y0, x1, y1 = kw["window"]
+                assert_bit_exact(hdr[y0:y1, x0:x1], ref_hdr[y0:y1, x0:x1], f"queue {case} depth {depth}")
+            elif "shard" in kw:
+                rows = dist.owned_rows(sd.height, *kw["shard"])
+                assert_bit_exact(hdr[rows], ref_hdr[rows], f"queue {case} depth {depth}")
+            else:
+                assert_bit_exact(hdr, ref_hdr, f"queue {case} depth {depth}, {frames} frames")
+                assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"]
+                assert c["scatter_events"] == ref_c["scatter_events"] and c["shadow_walks"] == ref_c["shadow_walks"]
+    finally:
+        hip_dev.set_option(abi.OPT_QUEUE, 1)
+
+
 @pytest.mark.parametrize("name,frames", [("c1", 4), ("c2", 2)])
 def test_baseline_configs_full_frame(hip_dev, name, frames):
     """BASELINE configs 0 and 1 (64^3 sphere at 256^2; 256^3 head at 512^2, one light) at their full image sizes:
