@@ -7,8 +7,16 @@ from oracle import binding
 from sunvolumerender_amd import abi, host, scenes
 
 
-def oracle_frames(scene, nframes, trace_depth=None, window=None, nthreads=0):
-    """Progressive frames 0..nframes-1 through the oracle.  Returns (hdr, img, counters)."""
+import os
+
+ORACLE_THREADS = int(os.environ.get("SVR_CPU_THREADS", "0")) or min(16, os.cpu_count() or 1)
+
+
+def oracle_frames(scene, nframes, trace_depth=None, window=None, nthreads=None):
+    """Progressive frames 0..nframes-1 through the oracle.  Returns (hdr, img, counters).
+    Threads: SVR_CPU_THREADS or min(16, cores) -- one GPU's CPU share of the test box; an OpenMP team of all 256 cores of
+    that box costs ~0.1 s per call on the small test frames."""
+    nthreads = ORACLE_THREADS if nthreads is None else nthreads
     o = binding.OracleScene(scene)
     hdr = o.new_hdr()
     img = np.zeros((o.H, o.W, 4), dtype=np.uint8)
