@@ -4,7 +4,7 @@
 Workload (BASELINE.json metric: "Msamples/sec at 1024^2 on 512^3 volume"): config c3 = 512^3 CT-like volume, 1024^2
 image, 3 area lights + environment map, GUI-default transfer function, trace depth 1 (the reference's default,
 gui/canvas.cpp:17).  A *step* is one complete progressive render of the configuration: `--spp-per-step` samples for
-every pixel (default 256 = c3's spp), issued as ONE svr_render_pathtracer_frames call = 8 trace launches of 32 frames,
+every pixel (default 256 = c3's spp), issued as ONE svr_render_pathtracer_frames call = 4 trace launches of 64 frames,
 bit-identical to 256 render_pathtracer calls (`--spp-per-step 1` is the reference's one-call-per-frame protocol).
 
 `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (torch.distributed.run,
@@ -30,7 +30,6 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
-import hashlib
 import json
 import os
 import socket
@@ -142,12 +141,10 @@ def _cpu_model() -> str:
 
 
 def kernel_source_hash() -> str:
-    """Hash of the kernel sources: a committed PMC record made from other sources is flagged as stale."""
-    h = hashlib.sha1()
-    for f in sorted((ROOT / "sunvolumerender_amd" / "csrc").glob("*")):
-        if f.suffix in (".hip", ".hpp"):
-            h.update(f.read_bytes())
-    return h.hexdigest()[:12]
+    """Hash of the kernel sources (comments and whitespace ignored): a committed PMC record made from other code is flagged as stale."""
+    from sunvolumerender_amd._build import kernel_source_hash as h
+
+    return h()
 
 
 def pmc_record(tag: str):

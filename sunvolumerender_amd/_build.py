@@ -43,6 +43,22 @@ HIPCC_FLAGS += os.environ.get("SVR_EXTRA_HIPCC_FLAGS", "").split()
 LINK_LIBS = ["-lz"]          # MetaImage CompressedData (svr_host_io.hip)
 
 
+def kernel_source_hash() -> str:
+    """Hash of the kernel sources with comments and whitespace removed: the PMC records under profiles/ carry it, and
+    bench.py flags a record made from other code as stale."""
+    import hashlib
+    import re
+
+    h = hashlib.sha1()
+    for f in sorted(CSRC.glob("*")):
+        if f.suffix in (".hip", ".hpp"):
+            text = f.read_text()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", "", text)
+            h.update(re.sub(r"\s+", "", text).encode())
+    return h.hexdigest()[:12]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if cand and Path(cand).exists():

@@ -397,22 +397,22 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                     if (++npend == QUEUE_TASKS || qcount + 64u > QUEUE_CAP) flush();
                     continue;
                 } else {
-                v3 L = V3(0.f, 0.f, 0.f);
-                if (live) {
-                    uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
-                    L = trace_path_tile<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, x, y, w.traceDepth, wang_hash(w.frame0 + slot), w.debug_stop, group_march, P2,
-                                                                     &gmaps[wave][0], c);
-                    if (!fold) {
-                        float* o = w.lbuf + (size_t)slot * w.slot_stride + 3 * ((size_t)y * s.imageW + x);
-                        o[0] = L.x; o[1] = L.y; o[2] = L.z;
+                    v3 L = V3(0.f, 0.f, 0.f);
+                    if (live) {
+                        uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
+                        L = trace_path_tile<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, x, y, w.traceDepth, wang_hash(w.frame0 + slot), w.debug_stop, group_march, P2,
+                                                                         &gmaps[wave][0], c);
+                        if (!fold) {
+                            float* o = w.lbuf + (size_t)slot * w.slot_stride + 3 * ((size_t)y * s.imageW + x);
+                            o[0] = L.x; o[1] = L.y; o[2] = L.z;
+                        }
                     }
-                }
-                if (fold) {
-                    float* pl_row = &pend.L[wave][npend * 3u][lane];
-                    pl_row[0] = L.x; pl_row[PEND_ROW] = L.y; pl_row[2u * PEND_ROW] = L.z;
-                    if (lane == 0) pend.task[wave][npend] = k;
-                    if (++npend == PEND_TASKS) flush();
-                }
+                    if (fold) {
+                        float* pl_row = &pend.L[wave][npend * 3u][lane];
+                        pl_row[0] = L.x; pl_row[PEND_ROW] = L.y; pl_row[2u * PEND_ROW] = L.z;
+                        if (lane == 0) pend.task[wave][npend] = k;
+                        if (++npend == PEND_TASKS) flush();
+                    }
                 }
             }
         }

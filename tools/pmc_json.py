@@ -3,7 +3,6 @@
 Usage: tools/pmc_json.py <summary.txt> <kernel-prefix> <tag> <out.json> [note]
 Counters are per-dispatch averages of separate rocprofv3 --pmc passes; FETCH_SIZE is doubled per the gfx950
 correction of MI355X_MICROARCH.md (HBM section)."""
-import hashlib
 import json
 import re
 import sys
@@ -25,12 +24,10 @@ for line in open(summary):
     m = re.match(r"(\S+)\s+calls=\s*(\d+)\s+total_ns=\s*(\d+)\s+avg_ns=\s*(\d+)", line)
     if m and m.group(1).startswith(kernel):
         stats = {"calls": int(m.group(2)), "avg_ns": int(m.group(4))}
-h = hashlib.sha1()
-for f in sorted((ROOT / "sunvolumerender_amd" / "csrc").glob("*")):
-    if f.suffix in (".hip", ".hpp"):
-        h.update(f.read_bytes())
+sys.path.insert(0, str(ROOT))
+from sunvolumerender_amd._build import kernel_source_hash  # noqa: E402
 rec = {"source": f"{summary} (rocprofv3 --kernel-trace --stats, then separate --pmc passes; per-dispatch averages)", "kernel": kernel, "tag": tag,
-       "note": note, "kernel_source_hash": h.hexdigest()[:12]}
+       "note": note, "kernel_source_hash": kernel_source_hash()}
 if stats:
     rec["rocprof_kernel_avg_ms"] = stats["avg_ns"] / 1e6
     rec["rocprof_kernel_calls"] = stats["calls"]
