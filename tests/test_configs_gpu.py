@@ -128,6 +128,56 @@ def test_c3_bench_shape_properties(c3):
         assert np.array_equal(ai, bi), what
 
 
+def test_c3_queue_machine_equals_straight_line_full_frame(c3, hip_dev):
+    """The scatter-record queue + per-lane state machine at FULL size (every wave drains many batches of 32 tasks, the
+    queues and radiance rows in global memory are reused batch after batch): forced on, it must reproduce the straight-line
+    paths bit for bit on the whole 1024^2 frame at traceDepth 1 (merged service) and 4 (separate services, its default
+    there), one 64-frame launch each; a window of the depth-4 frame is also checked against the oracle."""
+    try:
+        for depth in (1, 4):
+            c3.canvas.SetScatterTimes(depth)
+            hip_dev.set_option(abi.OPT_QUEUE, 0)
+            a, ai, _ = c3.run(64)
+            hip_dev.set_option(abi.OPT_QUEUE, 2)
+            b, bi, _ = c3.run(64)
+            assert_bit_exact(a, b, f"c3 depth {depth}: queue machine vs straight-line paths, full frame")
+            assert np.array_equal(ai, bi)
+        o = binding.OracleScene(c3.sc)
+        ref = o.new_hdr()
+        w = (480, 500, 544, 516)
+        for f in range(64):
+            o.render_pathtracer(ref, f, trace_depth=4, window=w, count=False, nthreads=THREADS)
+        x0, y0, x1, y1 = w
+        assert_bit_exact(b[y0:y1, x0:x1], ref[y0:y1, x0:x1], "c3 depth 4, queue machine vs oracle")
+    finally:
+        hip_dev.set_option(abi.OPT_QUEUE, 1)
+        c3.canvas.SetScatterTimes(1)
+
+
+def test_c3n_culling_and_queue_equal_plain_walks_full_frame(hip_dev):
+    """c3 with noisy non-zero air (the bench's second workload): majorant-bound culling and the queue machine (both on by
+    default there) against the same kernel with both off, whole frame, one 64-frame launch; a window against the oracle."""
+    r = Rig(hip_dev, "c3n")
+    try:
+        a, ai, _ = r.run(64)
+        hip_dev.set_option(abi.OPT_QUEUE, 0)
+        hip_dev.set_option(abi.OPT_BOUND_CULL, 0)
+        b, bi, _ = r.run(64)
+        assert_bit_exact(a, b, "c3n: culling + queue machine vs plain walks, full frame")
+        assert np.array_equal(ai, bi)
+        o = binding.OracleScene(r.sc)
+        ref = o.new_hdr()
+        w = (480, 500, 544, 508)
+        for f in range(64):
+            o.render_pathtracer(ref, f, window=w, count=False, nthreads=THREADS)
+        x0, y0, x1, y1 = w
+        assert_bit_exact(a[y0:y1, x0:x1], ref[y0:y1, x0:x1], "c3n vs oracle")
+    finally:
+        hip_dev.set_option(abi.OPT_QUEUE, 1)
+        hip_dev.set_option(abi.OPT_BOUND_CULL, 1)
+        r.close()
+
+
 # ------------------------------------------------------------------------------------------------------------
 # c4: 512^3 volume, 2048^2 image (BASELINE config 3; tiled across 8 GPUs there)
 # ------------------------------------------------------------------------------------------------------------
