@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void k_minmax(const uint16_t* __restrict__ src,
 
 __global__ __launch_bounds__(256) void k_empty_mask(const uint16_t* __restrict__ mm, uint32_t n_cells,
                                                     const uint32_t* __restrict__ zero_prefix, int tf_n,
-                                                    float densityScale, uint32_t* __restrict__ mask)
+                                                    float densityScale, uint32_t* __restrict__ mask, uint32_t* __restrict__ n_empty)
 {
     uint32_t m = blockIdx.x * 256u + threadIdx.x;
     if (m >= n_cells) return;
@@ -68,7 +68,12 @@ __global__ __launch_bounds__(256) void k_empty_mask(const uint16_t* __restrict__
     int e_hi = (int)__builtin_floorf(xh) + 2;             // the pair (e, e+1) of the upper end
     // zero_prefix[e] = number of entries < e of the padded alpha table that are exactly 0
     uint32_t zeros = zero_prefix[e_hi + 1] - zero_prefix[e_lo];
-    if (zeros == (uint32_t)(e_hi - e_lo + 1)) atomicOr(&mask[m >> 5], 1u << (m & 31u));
+    const bool empty = zeros == (uint32_t)(e_hi - e_lo + 1);
+    if (empty) atomicOr(&mask[m >> 5], 1u << (m & 31u));
+    if (n_empty != nullptr) {
+        const uint64_t b = __ballot(empty);
+        if (b != 0ull && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) atomicAdd(n_empty, (uint32_t)__popcll(b));
+    }
 }
 
 // MAJORANT-BOUND FETCH CULLING (bit-exact).  The reference's accept test is  xi < sigma_t * invSigmaMax
@@ -144,7 +149,7 @@ hipError_t launch_fine_mask(const uint16_t* mm, uint32_t n_cells, const uint32_t
 {
     hipError_t e = hipMemsetAsync(mask, 0, (size_t)words * 4u, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_empty_mask, dim3((n_cells + 255u) / 256u), dim3(256), 0, st, mm, n_cells, tf_zero_prefix, tf_n, densityScale, mask);
+    hipLaunchKernelGGL(k_empty_mask, dim3((n_cells + 255u) / 256u), dim3(256), 0, st, mm, n_cells, tf_zero_prefix, tf_n, densityScale, mask, (uint32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -153,7 +158,7 @@ hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const 
 {
     const int hgx = (gx + 1) / 2, hgy = (gy + 1) / 2, hgz = (gz + 1) / 2;
     const uint32_t hn = (uint32_t)hgx * (uint32_t)hgy * (uint32_t)hgz;
-    hipError_t e = hipMemsetAsync(accel + ACCEL_CLASS_OFF, 0, (size_t)(DIST_WORDS_MAX + BOUND_CLASSES + 2u) * 4u, st);
+    hipError_t e = hipMemsetAsync(accel + ACCEL_CLASS_OFF, 0, (size_t)(DIST_WORDS_MAX + BOUND_CLASSES + 2u) * 4u, st);   // (census words 2.. belong to launch_empty_mask)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_bound_class, dim3((hn + 255u) / 256u), dim3(256), 0, st, mm, gx, gy, gz, hgx, hgy, hgz, tf_rgba, tf_n, densityScale,
                        invSigmaMax, accel + ACCEL_CLASS_OFF, reinterpret_cast<float*>(accel + ACCEL_THR_OFF), accel + ACCEL_CENSUS_OFF);
@@ -242,7 +247,9 @@ hipError_t launch_empty_mask(const uint16_t* mm, int gx, int gy, int gz, const u
     hipError_t e = hipMemsetAsync(deep, 0, (size_t)(MASK_WORDS_MAX + mask_words) * 4u, st);
     if (e != hipSuccess) return e;
     const uint32_t blocks = (n_cells + 255u) / 256u;
-    hipLaunchKernelGGL(k_empty_mask, dim3(blocks), dim3(256), 0, st, mm, n_cells, tf_zero_prefix, tf_n, densityScale, empty);
+    e = hipMemsetAsync(mask + ACCEL_CENSUS_OFF + 2, 0, 8, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_empty_mask, dim3(blocks), dim3(256), 0, st, mm, n_cells, tf_zero_prefix, tf_n, densityScale, empty, mask + ACCEL_CENSUS_OFF + 2);
     uint8_t* a = tmp;
     uint8_t* b = tmp + n_cells;
     hipLaunchKernelGGL(k_dist_axis, dim3(blocks), dim3(256), 0, st, empty, (const uint8_t*)nullptr, a, gx, gy, gz, 0);

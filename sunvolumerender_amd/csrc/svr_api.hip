@@ -128,7 +128,7 @@ struct Context {
     bool mask_valid = false;
     uint64_t mask_vol = 0, mask_tf = 0, mask_tf_version = 0;
     uint32_t mask_ds_bits = 0, mask_sigma_bits = 0;
-    bool mask_cull_useful = false;
+    bool mask_cull_useful = false, mask_has_empty = true;
     uint32_t mask_words = 0;
     // ring of HIP event pairs around the path-tracing kernel (SVR_OPT_TIMING); drained lazily so the
     // timed launches never synchronise with the host
@@ -437,8 +437,9 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
         HIP_TRY(hipStreamSynchronize(g.stream));
         // the bound test costs two dependent LDS reads per tested cell (4 % on a scene where it never rejects anything): use
         // it where at least 2 % of the coarse cells that can hold a collision have a bound below 1
-        uint32_t census[2] = {0u, 0u};
+        uint32_t census[3] = {0u, 0u, 0u};
         HIP_TRY(hipMemcpy(census, g.d_mask + svr::ACCEL_CENSUS_OFF, sizeof census, hipMemcpyDeviceToHost));
+        g.mask_has_empty = census[2] != 0u;
         g.mask_cull_useful = (uint64_t)census[0] * 50u >= (uint64_t)census[0] + census[1] && census[0] != 0u;
         g.mask_valid = true; g.mask_vol = vol.tex; g.mask_tf = tf.tex; g.mask_tf_version = tt->version;
         g.mask_ds_bits = ds_bits; g.mask_sigma_bits = sg_bits; g.mask_words = words;
@@ -474,6 +475,7 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
     // would turn it on for cells >= 16 voxels)
     s.fine_mask = (tv->mm_fine && g.d_fine_mask && (g.opt_fine_mask == 2 || (g.opt_fine_mask == 1 && tv->mc_shift >= 4))) ? g.d_fine_mask : nullptr;
     s.fg_x = tv->fg_x; s.fg_y = tv->fg_y; s.fg_z = tv->fg_z; s.fg_xy = tv->fg_x * tv->fg_y;
+    s.has_empty = g.mask_has_empty ? 1u : 0u;
     s.bound_cull = (g.opt_bound_cull == 2 || (g.opt_bound_cull == 1 && g.mask_cull_useful)) ? 1u : 0u;
     s.park_end = (uint32_t)g.opt_park_end;
     return 0;

@@ -24,10 +24,10 @@ constexpr size_t PEND_FLOATS_PER_BLOCK = (size_t)QUEUE_TASKS * 3 * 64 * TILE_WAV
 // Bound classes (svr_accel.hip, k_bound_class): 4 bits per half-resolution macro-cell = smallest class c whose threshold
 // BOUND_THR(c) is >= (largest transfer-function alpha any fetch in the cell can return) x invSigmaMax.
 constexpr uint32_t BOUND_CLASSES = 16;
-constexpr uint32_t ACCEL_WORDS = DIST_WORDS_MAX + 2 * MASK_WORDS_MAX + DIST_WORDS_MAX + BOUND_CLASSES + 2;   // device buffer: dist | deep | empty | class | thresholds | census
+constexpr uint32_t ACCEL_WORDS = DIST_WORDS_MAX + 2 * MASK_WORDS_MAX + DIST_WORDS_MAX + BOUND_CLASSES + 4;   // device buffer: dist | deep | empty | class | thresholds | census
 constexpr uint32_t ACCEL_CLASS_OFF = DIST_WORDS_MAX + 2 * MASK_WORDS_MAX;
 constexpr uint32_t ACCEL_THR_OFF = ACCEL_CLASS_OFF + DIST_WORDS_MAX;
-constexpr uint32_t ACCEL_CENSUS_OFF = ACCEL_THR_OFF + BOUND_CLASSES;   // [0] coarse cells with a class in 1..14 (culling pays there), [1] cells of class 15
+constexpr uint32_t ACCEL_CENSUS_OFF = ACCEL_THR_OFF + BOUND_CLASSES;   // [0] coarse cells with a class in 1..14 (culling pays there), [1] cells of class 15, [2] `empty` macro-cells
 
 // counter slots (unsigned long long each) -- order of svr_counters in include/svr_abi.h
 enum { CNT_PATHS = 0, CNT_VOL_TAPS, CNT_WOODCOCK, CNT_SCATTER, CNT_SHADOW, CNT_RAYCAST, CNT_LOOP, CNT_TAPS_EXEC,

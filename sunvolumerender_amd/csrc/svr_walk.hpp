@@ -190,7 +190,8 @@ SVR_DEV CellInfo cell_info(const LDS& L, const DevScene& s, const Cell& c)
     uint32_t m = qx + __umul24(qy, (uint32_t)s.mc_gx) + __umul24(qz, (uint32_t)s.mc_gxy);
     m = inb ? m : 0u;
     CellInfo r;
-    r.empty = inb && ((L.emask[m >> 5] >> (m & 31u)) & 1u);
+    r.empty = false; r.deep = false;
+    if (s.has_empty) r.empty = inb && ((L.emask[m >> 5] >> (m & 31u)) & 1u);
     if (s.fine_mask != nullptr && inb && !r.empty) {
         // the coarse cell holds something somewhere: ask the fine level (cells of half the edge, global memory) about this spot
         const uint32_t fs = sh - 1u;
@@ -198,7 +199,7 @@ SVR_DEV CellInfo cell_info(const LDS& L, const DevScene& s, const Cell& c)
         const uint32_t f = fx + fy * (uint32_t)s.fg_x + fz * (uint32_t)s.fg_xy;
         r.empty = (s.fine_mask[f >> 5] >> (f & 31u)) & 1u;
     }
-    r.deep = WANT_DEEP ? (inb && ((L.mask[m >> 5] >> (m & 31u)) & 1u)) : false;
+    if (WANT_DEEP && s.has_empty) r.deep = inb && ((L.mask[m >> 5] >> (m & 31u)) & 1u);
     r.thr = u2f(SVR_INF_BITS);
     if constexpr (lds_has_cull<LDS>::value) {
         if (s.bound_cull) {
