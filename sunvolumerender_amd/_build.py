@@ -36,6 +36,7 @@ HIPCC_FLAGS = [
     "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall",
     "-Wno-unused-value",
+    "-fno-slp-vectorize",       # SLP packs adjacent f32 operations into v_pk_* instructions: an anti-lever on gfx950 (MI355X_MICROARCH.md); +2.6 % headline, +7 % at depth 4 (same-box A/B)
     "-I" + str(REPO_ROOT / "include"),
 ]
 # extra compile flags for experiment builds (e.g. -DSVR_TEST_HOOKS: the timing-ablation options of tools/exp.py)
