@@ -57,6 +57,7 @@ def kernel_source_hash() -> str:
             text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
             text = re.sub(r"//[^\n]*", "", text)
             h.update(re.sub(r"\s+", "", text).encode())
+    h.update(" ".join(f for f in HIPCC_FLAGS if not f.startswith("-I")).encode())      # the code generation flags are part of the code
     return h.hexdigest()[:12]
 
 
