@@ -15,9 +15,15 @@ constexpr uint32_t DIST_WORDS_MAX = 4096;   // words of the half-resolution 4-bi
 constexpr int DIST_CAP = 15;
 // QUEUE builds of the tile kernel (svr_trace_tile.hip, svr_lanes.hpp): per wave, up to QUEUE_CAP scatter records of REC_WORDS
 // words and the radiance of QUEUE_TASKS tasks (3 channels x 64 lanes), in global memory; TILE_WAVES waves per block
-constexpr uint32_t REC_WORDS = 14;      // pt(3) wo(3) val rng(6) id
-constexpr uint32_t QUEUE_TASKS = 32;
-constexpr uint32_t QUEUE_CAP = 1024;
+constexpr uint32_t REC_C1_WORDS = 17;   // traceDepth 1, a shaded scatter event waiting for its shadow walk: pt(3) wi(3) B(3) pdf rng(6) id|light
+constexpr uint32_t REC_A_WORDS = 26;    // deeper paths, after a next-event estimate: pt wo gradient colour(3 each) Pbrdf L(3) T(3) rng(6) meta
+constexpr uint32_t REC_B_WORDS = 20;    // deeper paths, at a scatter point: pt(3) wo(3) val L(3) T(3) rng(6) meta
+constexpr uint32_t REC_WORDS = REC_A_WORDS + REC_B_WORDS;   // words per record slot of a wave (the larger of the two uses)
+#ifndef SVR_QUEUE_TASKS
+#define SVR_QUEUE_TASKS 32
+#endif
+constexpr uint32_t QUEUE_TASKS = SVR_QUEUE_TASKS;
+constexpr uint32_t QUEUE_CAP = 32 * QUEUE_TASKS;
 constexpr uint32_t TILE_WAVES = 16;
 constexpr size_t QUEUE_WORDS_PER_BLOCK = (size_t)REC_WORDS * QUEUE_CAP * TILE_WAVES;
 constexpr size_t PEND_FLOATS_PER_BLOCK = (size_t)QUEUE_TASKS * 3 * 64 * TILE_WAVES;

@@ -53,46 +53,173 @@ SVR_DEV uint32_t lane_rank(uint64_t m)  // number of set bits of m below this la
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// queue of one wave: word j of record i at q[j * cap + i]
+// queue memory of one wave: word j of record i of a stack at base[j * cap + i]
 struct LaneQueue { uint32_t* q; uint32_t cap; };
 
-SVR_DEV void queue_push(const LaneQueue& Q, uint32_t& count, bool hit, v3 pt, v3 wo, float val, const Rng& rng, uint32_t id)
+// next-event estimate a shaded scatter event has prepared; its shadow walk decides whether the light arrives
+struct Nee { v3 wi; v3 B; float pdf; uint32_t light; bool have; };
+
+// VolumeSample + the light sampling of estimate_direct_light (pathtracer.cu:237-257, 171-190) for the scatter event at
+// vs.pt / vs.wo with intensity val: fills vs and the estimate; what follows is the shadow walk along ne.wi
+template <int LAYOUT, bool COUNT>
+SVR_DEV void shade_event(const DevScene& s, Shade& vs, float val, Rng& rng, Nee& ne, Cnt& c)
 {
-    const uint64_t m = __ballot(hit);
-    if (hit) {
-        uint32_t* p = Q.q + count + lane_rank(m);
-        const uint32_t cap = Q.cap;
-        p[0] = f2u(pt.x); p[cap] = f2u(pt.y); p[2 * cap] = f2u(pt.z);
-        p[3 * cap] = f2u(wo.x); p[4 * cap] = f2u(wo.y); p[5 * cap] = f2u(wo.z);
-        p[6 * cap] = f2u(val);
-        p[7 * cap] = rng.v0; p[8 * cap] = rng.v1; p[9 * cap] = rng.v2; p[10 * cap] = rng.v3; p[11 * cap] = rng.v4; p[12 * cap] = rng.d;
-        p[13 * cap] = id;
+    if (COUNT) { c.scatter++; c.taps += 7; c.exec += 6; }
+    tf_rgba(s, s.tf, val, vs.color);
+    {
+        // Gradient_CentralDiff, cuda_volume.h:54-61
+        const v3 q = vs.pt;
+        float xd = intensity_at<LAYOUT>(s, V3(q.x + s.spacing[0], q.y + 0.f, q.z + 0.f)) -
+                   intensity_at<LAYOUT>(s, V3(q.x - s.spacing[0], q.y - 0.f, q.z - 0.f));
+        float yd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + s.spacing[1], q.z + 0.f)) -
+                   intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - s.spacing[1], q.z - 0.f));
+        float zd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + 0.f, q.z + s.spacing[2])) -
+                   intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - 0.f, q.z - s.spacing[2]));
+        vs.gradient = V3((xd * 0.5f) * s.invSpacing[0], (yd * 0.5f) * s.invSpacing[1], (zd * 0.5f) * s.invSpacing[2]);
     }
-    count += (uint32_t)__popcll(m);
+    const float gradMag = __builtin_sqrtf(dot(vs.gradient, vs.gradient));
+    vs.Pbrdf = vs.color[3] * (1.f - expf_(s.pbrdf_c * gradMag * 65535.f * s.invMaxMagnitude));
+    vs.st = (rng_uniform(rng) < vs.Pbrdf) ? 1 : 0;
+    ne.have = false;
+    if (s.num_lights != 0) {
+        int li = (int)((float)s.num_lights * rng_uniform(rng));
+        li = li < (int)s.num_lights ? li : (int)s.num_lights - 1;
+        v3 Li;
+        if (sample_light(s.lights[li], vs.pt, rng, ne.wi, ne.pdf, Li)) {
+            ne.have = true;
+            ne.light = (uint32_t)li;
+            ne.B = bsdf_eval(vs, ne.wi);
+            if (COUNT) c.shadow++;
+        }
+    }
 }
 
-// Drain the wave's `count` records with all 64 lanes.  pendL: the wave's pending-radiance rows ([task * 3 + channel] of
-// pend_row floats, LDS or global); a finished path with id = (task << 6 | lane) stores its radiance at row
-// (id >> 6) * 3 + channel, column id & 63.
+// ---- records.  meta = id (12 bits: task << 6 | lane) | bounce k (15 bits) | light (4 bits) | shading type (1 bit)
+SVR_DEV uint32_t rec_meta(uint32_t id, uint32_t k, uint32_t light, int st) { return id | (k << 12) | (light << 27) | (st ? 0x80000000u : 0u); }
+SVR_DEV uint32_t meta_id(uint32_t m) { return m & 0xfffu; }
+SVR_DEV uint32_t meta_k(uint32_t m) { return (m >> 12) & 0x7fffu; }
+SVR_DEV uint32_t meta_light(uint32_t m) { return (m >> 27) & 0xfu; }
+SVR_DEV void rec_rng_store(uint32_t* p, uint32_t cap, const Rng& rng)
+{
+    p[0] = rng.v0; p[cap] = rng.v1; p[2 * cap] = rng.v2; p[3 * cap] = rng.v3; p[4 * cap] = rng.v4; p[5 * cap] = rng.d;
+}
+SVR_DEV void rec_rng_load(const uint32_t* p, uint32_t cap, Rng& rng)
+{
+    rng.v0 = p[0]; rng.v1 = p[cap]; rng.v2 = p[2 * cap]; rng.v3 = p[3 * cap]; rng.v4 = p[4 * cap]; rng.d = p[5 * cap];
+}
+SVR_DEV void rec_v3_store(uint32_t* p, uint32_t cap, v3 a) { p[0] = f2u(a.x); p[cap] = f2u(a.y); p[2 * cap] = f2u(a.z); }
+SVR_DEV v3 rec_v3_load(const uint32_t* p, uint32_t cap) { return V3(u2f(p[0]), u2f(p[cap]), u2f(p[2 * cap])); }
+// the 13 words of a shaded scatter event: pt wo gradient colour Pbrdf
+SVR_DEV void rec_shade_store(uint32_t* p, uint32_t cap, const Shade& vs)
+{
+    rec_v3_store(p, cap, vs.pt); rec_v3_store(p + 3 * cap, cap, vs.wo); rec_v3_store(p + 6 * cap, cap, vs.gradient);
+    p[9 * cap] = f2u(vs.color[0]); p[10 * cap] = f2u(vs.color[1]); p[11 * cap] = f2u(vs.color[2]);
+    p[12 * cap] = f2u(vs.Pbrdf);
+}
+SVR_DEV void rec_shade_load(const uint32_t* p, uint32_t cap, Shade& vs)
+{
+    vs.pt = rec_v3_load(p, cap); vs.wo = rec_v3_load(p + 3 * cap, cap); vs.gradient = rec_v3_load(p + 6 * cap, cap);
+    vs.color[0] = u2f(p[9 * cap]); vs.color[1] = u2f(p[10 * cap]); vs.color[2] = u2f(p[11 * cap]);
+    vs.Pbrdf = u2f(p[12 * cap]);
+}
+// A: a path after a next-event estimate; continues at the BSDF sampling (pathtracer.cu:259)
+SVR_DEV void rec_a_store(uint32_t* p, uint32_t cap, const Shade& vs, v3 L, v3 T, const Rng& rng, uint32_t meta)
+{
+    rec_shade_store(p, cap, vs);
+    rec_v3_store(p + 13 * cap, cap, L); rec_v3_store(p + 16 * cap, cap, T);
+    rec_rng_store(p + 19 * cap, cap, rng);
+    p[25 * cap] = meta;
+}
+SVR_DEV uint32_t rec_a_load(const uint32_t* p, uint32_t cap, Shade& vs, v3& L, v3& T, Rng& rng)
+{
+    rec_shade_load(p, cap, vs);
+    L = rec_v3_load(p + 13 * cap, cap); T = rec_v3_load(p + 16 * cap, cap);
+    rec_rng_load(p + 19 * cap, cap, rng);
+    const uint32_t meta = p[25 * cap];
+    vs.st = (int)(meta >> 31);
+    return meta;
+}
+// B: a path whose continuation walk found a collision; continues at the shading (pathtracer.cu:237)
+SVR_DEV void rec_b_store(uint32_t* p, uint32_t cap, v3 pt, v3 wo, float val, v3 L, v3 T, const Rng& rng, uint32_t meta)
+{
+    rec_v3_store(p, cap, pt); rec_v3_store(p + 3 * cap, cap, wo);
+    p[6 * cap] = f2u(val);
+    rec_v3_store(p + 7 * cap, cap, L); rec_v3_store(p + 10 * cap, cap, T);
+    rec_rng_store(p + 13 * cap, cap, rng);
+    p[19 * cap] = meta;
+}
+SVR_DEV uint32_t rec_b_load(const uint32_t* p, uint32_t cap, v3& pt, v3& wo, float& val, v3& L, v3& T, Rng& rng)
+{
+    pt = rec_v3_load(p, cap); wo = rec_v3_load(p + 3 * cap, cap);
+    val = u2f(p[6 * cap]);
+    L = rec_v3_load(p + 7 * cap, cap); T = rec_v3_load(p + 10 * cap, cap);
+    rec_rng_load(p + 13 * cap, cap, rng);
+    return p[19 * cap];
+}
+// C1 (traceDepth 1): the first scatter event of a path, shaded, waiting for its shadow walk -- nothing follows that walk but the estimate itself
+SVR_DEV void rec_c1_store(uint32_t* p, uint32_t cap, v3 pt, const Nee& ne, const Rng& rng, uint32_t id)
+{
+    rec_v3_store(p, cap, pt); rec_v3_store(p + 3 * cap, cap, ne.wi); rec_v3_store(p + 6 * cap, cap, ne.B);
+    p[9 * cap] = f2u(ne.pdf);
+    rec_rng_store(p + 10 * cap, cap, rng);
+    p[16 * cap] = rec_meta(id, 0u, ne.light, 0);
+}
+SVR_DEV uint32_t rec_c1_load(const uint32_t* p, uint32_t cap, v3& pt, Nee& ne, Rng& rng)
+{
+    pt = rec_v3_load(p, cap); ne.wi = rec_v3_load(p + 3 * cap, cap); ne.B = rec_v3_load(p + 6 * cap, cap);
+    ne.pdf = u2f(p[9 * cap]);
+    rec_rng_load(p + 10 * cap, cap, rng);
+    const uint32_t meta = p[16 * cap];
+    ne.light = meta_light(meta);
+    return meta;
+}
+// the wave's queue memory: traceDepth 1: C1 records; deeper: stacks A | B
+SVR_DEV uint32_t* queue_c(const LaneQueue& Q) { return Q.q; }
+SVR_DEV uint32_t* queue_a(const LaneQueue& Q) { return Q.q; }
+SVR_DEV uint32_t* queue_b(const LaneQueue& Q) { return Q.q + (size_t)REC_A_WORDS * Q.cap; }
+
+// The wave hands its first scatter events to the queue: ballot + mbcnt prefix sum, so the records are dense and the stores
+// coalesce.  traceDepth 1: shaded events that have a light sample (the others are over with L = 0: the caller stores it).
+SVR_DEV void queue_push_c1(const LaneQueue& Q, uint32_t& nC, bool live, v3 pt, const Nee& ne, const Rng& rng, uint32_t id)
+{
+    const uint64_t m = __ballot(live);
+    if (live) rec_c1_store(queue_c(Q) + nC + lane_rank(m), Q.cap, pt, ne, rng, id);
+    nC += (uint32_t)__popcll(m);
+}
+// deeper: paths after the next-event estimate of their first scatter event
+SVR_DEV void queue_push_a(const LaneQueue& Q, uint32_t& nA, bool live, const Shade& vs, v3 L, const Rng& rng, uint32_t id)
+{
+    const uint64_t m = __ballot(live);
+    if (live) rec_a_store(queue_a(Q) + nA + lane_rank(m), Q.cap, vs, L, V3(1.f, 1.f, 1.f), rng, rec_meta(id, 0u, 0u, vs.st));
+    nA += (uint32_t)__popcll(m);
+}
+
+#ifndef SVR_PARK_CHEAP
+#define SVR_PARK_CHEAP 16
+#endif
+
+// Drain the wave's records (traceDepth 1: nC shaded first events; deeper: nA paths waiting for the BSDF sampling) with all 64 lanes.  pendL: the
+// wave's pending-radiance rows ([task * 3 + channel] of pend_row floats); a finished path with id = (task << 6 | lane)
+// stores its radiance at row (id >> 6) * 3 + channel, column id & 63.
 template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS>
-SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, uint32_t count, uint32_t traceDepth_, float* pendL, uint32_t pend_row, Cnt& c,
+SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, uint32_t nC, uint32_t nA, uint32_t traceDepth_, float* pendL, uint32_t pend_row, Cnt& c,
                          unsigned long long* c_prof = nullptr)
 {
-    enum : uint32_t { IDLE = 0u, SHADE = 1u, WALK = 2u, FETCH = 3u, MARCH = 4u, END = 5u };
+    enum : uint32_t { IDLE = 0u, WALK = 2u, FETCH = 3u, MARCH = 4u, END = 5u, WANT_A = 6u, WANT_B = 7u };
     const float INF = u2f(SVR_INF_BITS);
     const uint32_t traceDepth = DEPTH1 ? 1u : traceDepth_;
-    uint32_t next = 0u;                       // wave-uniform: next record to pop
     uint32_t st = IDLE;
     // walk state
     Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
     v3 orig = V3(0.f, 0.f, 0.f), dir = V3(0.f, 0.f, 1.f);
     float t = 0.f, tMin = 0.f, tMax = 0.f, t_occ = 0.f, xi = 0.f, val = 0.f;
     uint32_t clear_run = 0u, guard = 0u;
-    bool shadow = false, rng_live = false, hit = false, have_light = false, tail_counted = false, ray_skippable = false;
+    bool shadow = false, rng_live = false, hit = false, tail_counted = false, ray_skippable = false;
     // path state
-    uint32_t id = 0u, k = 0u, lightId = 0u;
-    v3 L = V3(0.f, 0.f, 0.f), T = V3(1.f, 1.f, 1.f), B = V3(0.f, 0.f, 0.f);
-    float pdfL = 1.f;
+    uint32_t id = 0u, k = 0u;
+    v3 L = V3(0.f, 0.f, 0.f), T = V3(1.f, 1.f, 1.f);
+    Nee ne;
+    ne.wi = dir; ne.B = L; ne.pdf = 1.f; ne.light = 0u; ne.have = false;
     Shade vs;
     vs.pt = orig; vs.wo = dir; vs.gradient = dir; vs.color[0] = vs.color[1] = vs.color[2] = vs.color[3] = 0.f; vs.Pbrdf = 0.f; vs.st = 0;
 
@@ -136,10 +263,10 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
     };
 
     // the services of a walking lane that cannot wait: the fetch an iteration asked for, the re-march after an occupied stretch
-    auto serve_fetch_march = [&](bool mine) {
+    auto serve_fetch_march = [&]() {
         // FETCH: 8 voxels + filter + LUT, then the accept test with the draw the lane kept
-        if (__ballot(mine && st == FETCH) != 0ull) {
-            if (mine && st == FETCH) {
+        if (__ballot(st == FETCH) != 0ull) {
+            if (st == FETCH) {
                 if (COUNT) c.exec++;
                 val = tex_fetch<LAYOUT>(s, cell_of(s, orig + dir * t)) * s.densityScale;
                 const float sigma_t = alpha_of(L_, s, val);
@@ -148,8 +275,8 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
             }
         }
         // MARCH: the walk has left an occupied stretch: where is the next one?
-        if (SKIP && __ballot(mine && st == MARCH) != 0ull) {
-            if (mine && st == MARCH) {
+        if (SKIP && __ballot(st == MARCH) != 0ull) {
+            if (st == MARCH) {
                 t_occ = first_occupied(s, L_, orig, dir, t, tMax);
                 clear_run = 0u;
                 st = WALK;
@@ -166,183 +293,194 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
         o[0] = L.x; o[pend_row] = L.y; o[2u * pend_row] = L.z;
         st = IDLE;
     };
-    // END of a CONTINUATION walk (pathtracer.cu:231-244): no collision -> the path is over; collision -> the next scatter point
-    auto end_continuation = [&]() {
-        if (!hit) {
-            if (s.env_on_escape) L = L + T * env_radiance(s, dir);
-            finish();
-        } else {
-            vs.wo = -dir;
-            vs.pt = orig + dir * t;
-            st = SHADE;
-        }
+    // END of a SHADOW walk (pathtracer.cu:191-198): transmittance -> direct light
+    auto nee = [&]() {
+        // transmittance.h:15-16 on the walk's result ts (t, or -FLT_MAX), with the box interval of the shadow ray
+        const float ts = hit ? t : -SVR_FLT_MAX;
+        const float Tr = ((ts > tMin) && (ts < tMax)) ? 0.f : 1.f;
+        const float kf = Tr * (float)s.num_lights;
+        const DevLight& l = s.lights[ne.light];
+        const v3 Li = V3(l.radiance[0], l.radiance[1], l.radiance[2]);     // sample_light returned true: cosTerm > 0
+        L = L + T * (((ne.B * kf) * Li) / ne.pdf);
     };
-    // END of a SHADOW walk (pathtracer.cu:191-198, 258-276): transmittance -> direct light, then the next bounce's direction and walk
-    auto end_shadow = [&]() {
-        v3 Ld = V3(0.f, 0.f, 0.f);
-        if (have_light) {
-            // transmittance.h:15-16 on the walk's result ts (t, or -FLT_MAX), with the box interval of the shadow ray
-            const float ts = hit ? t : -SVR_FLT_MAX;
-            const float Tr = ((ts > tMin) && (ts < tMax)) ? 0.f : 1.f;
-            const float kf = Tr * (float)s.num_lights;
-            const DevLight& l = s.lights[lightId];
-            const v3 Li = V3(l.radiance[0], l.radiance[1], l.radiance[2]);     // sample_light returned true: cosTerm > 0
-            Ld = ((B * kf) * Li) / pdfL;
-        }
-        L = L + T * Ld;
-        if (k + 1u >= traceDepth) { finish(); return; }                 // sample_bsdf / roulette of the last bounce cannot reach L
-        v3 wi; float pdf = 0.f;
-        const v3 f = bsdf_sample(vs, wi, pdf, rng);
-        const float cosTerm = __builtin_fabsf(dot(normalize(vs.gradient), wi));
-        if (fmax_(f.x, fmax_(f.y, f.z)) > 0.f && pdf > 0.f) {
-            if (vs.st == 0) T = T * (f / (pdf * (1.f - vs.Pbrdf)));
-            else T = T * ((f * cosTerm) / (pdf * vs.Pbrdf));
-        }
+    // the shadow walk of the prepared estimate; the draws of sample_bsdf / roulette follow it unless this is the last bounce
+    auto begin_shadow = [&]() {
         orig = vs.pt;
-        dir = wi;
-        if (k >= 3u && russian_roulette(T, rng)) { finish(); return; }
-        ++k;
-        begin_walk(false, false);                                       // the next bounce's walk (pathtracer.cu:218)
-        if (st == END) {                                                // its result is known: no collision
-            if (s.env_on_escape) L = L + T * env_radiance(s, dir);
-            finish();
-        }
-    };
-    // SHADE: VolumeSample + next-event estimation up to the shadow walk (pathtracer.cu:237-257, 171-191)
-    auto shade = [&]() {
-        if (COUNT) { c.scatter++; c.taps += 7; c.exec += 6; }
-        tf_rgba(s, s.tf, val, vs.color);
-        {
-            // Gradient_CentralDiff, cuda_volume.h:54-61
-            const v3 q = vs.pt;
-            float xd = intensity_at<LAYOUT>(s, V3(q.x + s.spacing[0], q.y + 0.f, q.z + 0.f)) -
-                       intensity_at<LAYOUT>(s, V3(q.x - s.spacing[0], q.y - 0.f, q.z - 0.f));
-            float yd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + s.spacing[1], q.z + 0.f)) -
-                       intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - s.spacing[1], q.z - 0.f));
-            float zd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + 0.f, q.z + s.spacing[2])) -
-                       intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - 0.f, q.z - s.spacing[2]));
-            vs.gradient = V3((xd * 0.5f) * s.invSpacing[0], (yd * 0.5f) * s.invSpacing[1], (zd * 0.5f) * s.invSpacing[2]);
-        }
-        const float gradMag = __builtin_sqrtf(dot(vs.gradient, vs.gradient));
-        vs.Pbrdf = vs.color[3] * (1.f - expf_(s.pbrdf_c * gradMag * 65535.f * s.invMaxMagnitude));
-        vs.st = (rng_uniform(rng) < vs.Pbrdf) ? 1 : 0;
-        // estimate_direct_light, pathtracer.cu:171-198
-        have_light = false;
-        orig = vs.pt;
-        st = END; shadow = true; hit = false;
-        if (s.num_lights != 0) {
-            int li = (int)((float)s.num_lights * rng_uniform(rng));
-            li = li < (int)s.num_lights ? li : (int)s.num_lights - 1;
-            v3 wiL, Li;
-            if (sample_light(s.lights[li], vs.pt, rng, wiL, pdfL, Li)) {
-                have_light = true;
-                lightId = (uint32_t)li;
-                B = bsdf_eval(vs, wiL);
-                if (COUNT) c.shadow++;
-                dir = wiL;
-                // the draws of sample_bsdf / roulette follow the shadow walk unless this is the last bounce
-                begin_walk(true, k + 1u < traceDepth);
-            }
-        }
+        dir = ne.wi;
+        begin_walk(true, k + 1u < traceDepth);
     };
 
-    // refill the idle lanes from the queue: a popped record is a path at its first scatter point
-    auto refill = [&]() {
-        const uint64_t idle = __ballot(st == IDLE);
-        if (idle == 0ull || next >= count) return;
-        PROF_BEGIN(pr, PH_REFILL);
-        const uint32_t n_idle = (uint32_t)__popcll(idle);
-        const uint32_t i = next + lane_rank(idle);
-        if (st == IDLE && i < count) {
-            const uint32_t* p = Q.q + i;
-            const uint32_t cap = Q.cap;
-            vs.pt = V3(u2f(p[0]), u2f(p[cap]), u2f(p[2 * cap]));
-            vs.wo = V3(u2f(p[3 * cap]), u2f(p[4 * cap]), u2f(p[5 * cap]));
-            val = u2f(p[6 * cap]);
-            rng.v0 = p[7 * cap]; rng.v1 = p[8 * cap]; rng.v2 = p[9 * cap]; rng.v3 = p[10 * cap]; rng.v4 = p[11 * cap]; rng.d = p[12 * cap];
-            id = p[13 * cap];
-            L = V3(0.f, 0.f, 0.f); T = V3(1.f, 1.f, 1.f); k = 0u;
-            st = SHADE;
-        }
-        PROF_END(pr, min(n_idle, count - next));
-        next = min(count, next + n_idle);
-    };
-
-    // Scheduling (phase profiles of experiment builds, c3 at traceDepth 4): the services (END: end of a shadow walk + BSDF
-    // sampling + next walk's set-up; SHADE) cost ~10^3 instructions each, the same for 1 lane or 64.  Serving as soon as 16
-    // lanes waited ran them at 30-40 % lane utilisation and 65 % of the drain's time; serving only when NO lane can walk
-    // (strict generations) ran them at 90-99 % but left the wave waiting for its few longest walks (51 % of the time at 7
-    // walking lanes).  So a service runs when park_end lanes wait for it, or when nobody walks.
-    const uint32_t park_end = s.park_end;
+    const uint32_t park_cheap = SVR_PARK_CHEAP;
     if constexpr (DEPTH1) {
-        // traceDepth 1: a path is over when its shadow walk is, so ONE service takes every waiting lane through
-        // [end of walk -> radiance -> next record -> shading -> next shadow walk] (c3: 8032 against 7336 Msamples/s for two
-        // separately triggered services, 7763 for straight-line paths)
+        // traceDepth 1: the machine only walks -- pop a shaded event, shadow walk, radiance -- so its rounds are cheap
+        // (~10^2 instructions) and run as soon as a few lanes wait
+        uint32_t next = 0u;
         for (;;) {
             PROF_BEGIN(pw, PH_CHEAP);
             while (__ballot(st == WALK) != 0ull) {
-                if ((uint32_t)__popcll(__ballot(st == END || st == SHADE || (st == IDLE && next < count))) >= park_end) break;
+                if ((uint32_t)__popcll(__ballot(st == END)) + min((uint32_t)__popcll(__ballot(st == IDLE)), nC - next) >= park_cheap) break;
                 if (st == WALK) iterate();
-                serve_fetch_march(true);
+                serve_fetch_march();
             }
             PROF_END(pw, 32u);
-            if (__ballot(st == END) != 0ull) {
-                PROF_BEGIN(pe, PH_END);
-                if (st == END) end_shadow();
-                PROF_END(pe, 32u);
-            }
-            refill();
-            {
-                const uint64_t m = __ballot(st == SHADE);
-                if (m != 0ull) {
-                    PROF_BEGIN(ps, PH_SHADE);
-                    if (st == SHADE) shade();
-                    PROF_END(ps, (uint32_t)__popcll(m));
+            PROF_BEGIN(pe, PH_END);
+            if (st == END) { nee(); finish(); }
+            if (next < nC) {
+                const uint64_t idle = __ballot(st == IDLE);
+                const uint32_t i = next + lane_rank(idle);
+                if (st == IDLE && i < nC) {
+                    id = meta_id(rec_c1_load(queue_c(Q) + i, Q.cap, vs.pt, ne, rng));
+                    L = V3(0.f, 0.f, 0.f); T = V3(1.f, 1.f, 1.f); k = 0u;
+                    begin_shadow();
                 }
+                next = min(nC, next + (uint32_t)__popcll(idle));
             }
-            if (__ballot(st != IDLE) == 0ull) break;
+            PROF_END(pe, 32u);
+            if (next >= nC && __ballot(st != IDLE) == 0ull) break;
         }
     } else {
-        // deeper paths: the two services are triggered separately and the continuation walks (a few iterations inside the
-        // medium) run in the common walk loop -- taking the served lanes through [end -> continuation walk -> end -> shading]
-        // in one go with the walks in flight paused was slower (c3 depth 2 / 4: 2977 / 1996 against 3784 / 2491 Msamples/s)
+        // Deeper paths: a lane holds a path only while it walks.  When the walk is over the lane settles its result (radiance
+        // of the shadow ray; collision or escape of the continuation) and the path WAITS FOR A SERVICE, of which there are
+        // two: A = BSDF sampling + throughput + roulette + the next walk's set-up, B = shading + light sampling + the shadow
+        // walk's set-up (~10^3 instructions, the same for 1 lane or 64).  With the waiting paths kept in their lanes, the
+        // lanes of a wave were split between walking, waiting for A, waiting for B and waiting for a record, each service
+        // was triggered on its own count, and 15 of 64 lanes walked on average (c3, traceDepth 4).  So waiting paths go
+        // to memory instead -- one stack per service -- and a round of services takes ALL non-walking lanes through the
+        // service with more paths waiting (lanes that already hold such a path keep it, the rest push theirs and pop).
+        uint32_t nB = 0u;
+        uint32_t* const qa = queue_a(Q);
+        uint32_t* const qb = queue_b(Q);
+        // after the next-event estimate of bounce k (pathtracer.cu:258-276): the next direction, the throughput, roulette,
+        // and the next bounce's walk
+        auto bounce = [&]() {
+            v3 wi; float pdf = 0.f;
+            const v3 f = bsdf_sample(vs, wi, pdf, rng);
+            const float cosTerm = __builtin_fabsf(dot(normalize(vs.gradient), wi));
+            if (fmax_(f.x, fmax_(f.y, f.z)) > 0.f && pdf > 0.f) {
+                if (vs.st == 0) T = T * (f / (pdf * (1.f - vs.Pbrdf)));
+                else T = T * ((f * cosTerm) / (pdf * vs.Pbrdf));
+            }
+            orig = vs.pt;
+            dir = wi;
+            if (k >= 3u && russian_roulette(T, rng)) { finish(); return; }
+            ++k;
+            begin_walk(false, false);                                       // the next bounce's walk (pathtracer.cu:218)
+            if (st == END) {                                                // its result is known: no collision
+                if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+                finish();
+            }
+        };
+        // a shaded event without a light sample has no shadow walk: its estimate is settled
+        auto after_shade = [&]() {
+            if (ne.have) begin_shadow();
+            else if (k + 1u >= traceDepth) finish();
+            else st = WANT_A;
+        };
+        auto fence = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // records are written and read by different lanes of this wave
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        auto push_a = [&]() {
+            const uint64_t m = __ballot(st == WANT_A);
+            if (m == 0ull) return;
+            if (st == WANT_A) { rec_a_store(qa + nA + lane_rank(m), Q.cap, vs, L, T, rng, rec_meta(id, k, 0u, vs.st)); st = IDLE; }
+            nA += (uint32_t)__popcll(m);
+        };
+        auto push_b = [&]() {
+            const uint64_t m = __ballot(st == WANT_B);
+            if (m == 0ull) return;
+            if (st == WANT_B) { rec_b_store(qb + nB + lane_rank(m), Q.cap, vs.pt, vs.wo, val, L, T, rng, rec_meta(id, k, 0u, 0)); st = IDLE; }
+            nB += (uint32_t)__popcll(m);
+        };
+        // pops: the idle lanes take the newest records (still in the L2)
+        auto pop_a = [&]() {
+            const uint64_t idle = __ballot(st == IDLE);
+            const uint32_t r = lane_rank(idle);
+            fence();
+            if (st == IDLE && r < nA) {
+                const uint32_t meta = rec_a_load(qa + (nA - 1u - r), Q.cap, vs, L, T, rng);
+                id = meta_id(meta); k = meta_k(meta);
+                st = WANT_A;
+            }
+            nA -= min(nA, (uint32_t)__popcll(idle));
+        };
+        auto pop_b = [&]() {
+            const uint64_t idle = __ballot(st == IDLE);
+            const uint32_t r = lane_rank(idle);
+            fence();
+            if (st == IDLE && r < nB) {
+                const uint32_t meta = rec_b_load(qb + (nB - 1u - r), Q.cap, vs.pt, vs.wo, val, L, T, rng);
+                id = meta_id(meta); k = meta_k(meta);
+                st = WANT_B;
+            }
+            nB -= min(nB, (uint32_t)__popcll(idle));
+        };
+        auto serve_a = [&]() {
+            const uint64_t m = __ballot(st == WANT_A);
+            if (m == 0ull) return;
+            PROF_BEGIN(pe, PH_END);
+            if (st == WANT_A) bounce();
+            PROF_END(pe, (uint32_t)__popcll(m));
+        };
+        auto serve_b = [&]() {
+            const uint64_t m = __ballot(st == WANT_B);
+            if (m == 0ull) return;
+            PROF_BEGIN(ps, PH_SHADE);
+            if (st == WANT_B) { shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c); after_shade(); }
+            PROF_END(ps, (uint32_t)__popcll(m));
+        };
+        const uint32_t park_end = s.park_end;
         for (;;) {
             PROF_BEGIN(pw, PH_CHEAP);
 #if SVR_PROF
             uint32_t pc_it = 0u, pc_walk = 0u;
 #endif
             while (__ballot(st == WALK) != 0ull) {
-                if ((uint32_t)__popcll(__ballot(st == END)) >= park_end) break;
-                if ((uint32_t)__popcll(__ballot(st == SHADE || (st == IDLE && next < count))) >= park_end) break;
+                // lanes a round of services could put to work
+                const uint32_t n_end = (uint32_t)__popcll(__ballot(st == END)), n_idle = (uint32_t)__popcll(__ballot(st == IDLE));
+                if (n_end + min(n_idle, nA + nB) >= park_end) break;
 #if SVR_PROF
                 pc_it++; pc_walk += (uint32_t)__popcll(__ballot(st == WALK));
 #endif
                 if (st == WALK) iterate();
-                serve_fetch_march(true);
+                serve_fetch_march();
             }
 #if SVR_PROF
             PROF_END(pw, pc_it ? pc_walk / pc_it : 0u);
             if ((threadIdx.x & 63u) == 0u) { atomicAdd(&c_prof[2 * PH_N], (unsigned long long)pc_it); atomicAdd(&c_prof[2 * PH_N + 1], (unsigned long long)pc_walk); }
 #endif
-            const bool walking = __ballot(st == WALK) != 0ull;
-            {
-                const uint64_t m = __ballot(st == END);
-                if (m != 0ull && (!walking || (uint32_t)__popcll(m) >= park_end)) {
-                    PROF_BEGIN(pe, PH_END);
-                    if (st == END) { if (shadow) end_shadow(); else end_continuation(); }
-                    PROF_END(pe, (uint32_t)__popcll(m));
-                    if (__ballot(st == WALK) != 0ull) continue;        // the next bounce's walks first: their hits join the shading below
+            // settle the walks that are over
+            if (__ballot(st == END) != 0ull) {
+                PROF_BEGIN(pr, PH_REFILL);
+                if (st == END) {
+                    if (shadow) {
+                        nee();
+                        if (k + 1u >= traceDepth) finish();            // sample_bsdf / roulette of the last bounce cannot reach L
+                        else st = WANT_A;
+                    } else if (!hit) {                                  // pathtracer.cu:231-236
+                        if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+                        finish();
+                    } else {
+                        vs.wo = -dir;
+                        vs.pt = orig + dir * t;
+                        st = WANT_B;
+                    }
                 }
+                PROF_END(pr, 32u);
             }
-            const bool shade_now = !walking || (uint32_t)__popcll(__ballot(st == SHADE || (st == IDLE && next < count))) >= park_end;
-            if (shade_now) refill();
-            {
-                const uint64_t m = __ballot(st == SHADE);
-                if (m == 0ull && !walking && __ballot(st != IDLE) == 0ull) break;   // no walk, no end, no record, nothing to shade: the queue is drained
-                if (m == 0ull || !shade_now) continue;
-                PROF_BEGIN(ps, PH_SHADE);
-                if (st == SHADE) shade();
-                PROF_END(ps, (uint32_t)__popcll(m));
+            const uint32_t cA = nA + (uint32_t)__popcll(__ballot(st == WANT_A));
+            const uint32_t cB = nB + (uint32_t)__popcll(__ballot(st == WANT_B));
+            if (cA + cB == 0u) {
+                if (__ballot(st == WALK) == 0ull) break;                 // no walk, no waiting path, no record: the queue is drained
+                continue;
+            }
+            if (cB >= cA) {
+                push_a(); pop_b(); serve_b();
+                // the other service, for the lanes still idle, if they are many or nothing else can run
+                if (nA != 0u && ((uint32_t)__popcll(__ballot(st == IDLE)) >= park_end || __ballot(st == WALK) == 0ull)) { pop_a(); serve_a(); }
+            } else {
+                push_b(); pop_a(); serve_a();
+                if (nB != 0u && ((uint32_t)__popcll(__ballot(st == IDLE)) >= park_end || __ballot(st == WALK) == 0ull)) { pop_b(); serve_b(); }
             }
         }
     }

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
     const uint32_t n_units = (n_tasks + unit - 1u) / unit;
     const uint32_t shard0 = blockIdx.x % TICKET_SHARDS;
     const bool fold = w.fold != 0u;                               // host guarantees fgroups == 1 then
-    uint32_t npend = 0, qcount = 0;
+    uint32_t npend = 0, qC = 0, qA = 0;
     LaneQueue Q;
     Q.cap = QUEUE_CAP;
     Q.q = QUEUE ? w.queue + (size_t)(blockIdx.x * TILE_WAVES + wave) * (REC_WORDS * QUEUE_CAP) : nullptr;
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
         if constexpr (QUEUE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // records and radiance are read back by other lanes of this wave
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, Q, qcount, w.traceDepth, gpend, 64u, c, w.counters + CNT_N);
-            qcount = 0;
+            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, Q, qC, qA, w.traceDepth, gpend, 64u, c, w.counters + CNT_N);
+            qC = qA = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #if SVR_PROF
@@ -375,26 +375,63 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 // shared whole-ray test: >= 8 frames of a pixel in the wave, every lane alive (the group shuffles)
                 const bool group_march = SKIP && fl2 >= 3u && (!SVR_DEBUG_STOPS || w.debug_stop == 0u || w.debug_stop >= 3u) && __ballot(live) == ~0ull;
                 if constexpr (QUEUE) {
+                    // primary walk, then the hits' first scatter events are shaded in place -- the lanes are frames of the
+                    // same pixels and scatter together.  traceDepth 1: the shaded events are queued for their shadow walks.
+                    // Deeper: the shadow walk runs in place too (queueing it as well was slower: c3 depth 2 / 4, 4174 / 2602
+                    // against 4380 / 2720 Msamples/s) and the path is queued at its BSDF sampling.
                     Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
-                    v3 L = V3(0.f, 0.f, 0.f), pt = L, wo = L;
-                    float val = 0.f;
+                    v3 L = V3(0.f, 0.f, 0.f);
                     bool hit = false;
+                    float val = 0.f;
+                    Shade vs;
+                    vs.pt = L; vs.wo = L; vs.gradient = L; vs.color[0] = vs.color[1] = vs.color[2] = vs.color[3] = 0.f; vs.Pbrdf = 0.f; vs.st = 0;
+                    Nee ne;
+                    ne.wi = L; ne.B = L; ne.pdf = 1.f; ne.light = 0u; ne.have = false;
 #if SVR_PROF
                     unsigned long long* c_prof = w.counters + CNT_N;
 #endif
                     PROF_BEGIN(pa, PH_PRIMARY);
                     if (live) {
                         uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
-                        hit = trace_primary<LAYOUT, COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, pt, wo, val);
+                        hit = trace_primary<LAYOUT, COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, vs.pt, vs.wo, val);
                     }
                     PROF_END(pa, (uint32_t)__popcll(__ballot(live)));
-                    if (!hit) {
+                    {
+                        const uint64_t mh = __ballot(hit);
+                        if (mh != 0ull) {
+                            PROF_BEGIN(psh, PH_SHADE);
+                            if (hit) {
+                                shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
+                                if constexpr (!DEPTH1) {
+                                    if (ne.have) {
+                                        // estimate_direct_light, pathtracer.cu:191-198; the draws of sample_bsdf follow the
+                                        // shadow walk, so it consumes every draw up to the box exit
+                                        float sMin = (float)1e-6, sMax = SVR_FLT_MAX, sval = 0.f;
+                                        const float ts = walk<LAYOUT, COUNT, SKIP, SVR_SHADOW_REMARCH>(s, lds, vs.pt, ne.wi, rng, sMin, sMax, sval, true, c);
+                                        const float Tr = ((ts > sMin) && (ts < sMax)) ? 0.f : 1.f;          // transmittance.h:15-16
+                                        const float kf = Tr * (float)s.num_lights;
+                                        const DevLight& l = s.lights[ne.light];
+                                        L = L + V3(1.f, 1.f, 1.f) * (((ne.B * kf) * V3(l.radiance[0], l.radiance[1], l.radiance[2])) / ne.pdf);
+                                    }
+                                }
+                            }
+                            PROF_END(psh, (uint32_t)__popcll(mh));
+                        }
+                    }
+                    bool over;
+                    if constexpr (DEPTH1) {
+                        queue_push_c1(Q, qC, hit && ne.have, vs.pt, ne, rng, (npend << 6) | lane);
+                        over = !(hit && ne.have);                     // the camera ray's radiance, or a first event no light sample reaches (L = 0)
+                    } else {
+                        queue_push_a(Q, qA, hit, vs, L, rng, (npend << 6) | lane);
+                        over = !hit;
+                    }
+                    if (over) {
                         float* o = gpend + (size_t)npend * (3u * 64u) + lane;
                         o[0] = L.x; o[64] = L.y; o[128] = L.z;
                     }
-                    queue_push(Q, qcount, hit, pt, wo, val, rng, (npend << 6) | lane);
                     if (lane == 0) pend.task[wave][npend] = k;
-                    if (++npend == QUEUE_TASKS || qcount + 64u > QUEUE_CAP) flush();
+                    if (++npend == QUEUE_TASKS || qC + qA + 64u > QUEUE_CAP) flush();
                     continue;
                 } else {
                     v3 L = V3(0.f, 0.f, 0.f);
@@ -457,7 +494,7 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
     if (e != hipSuccess) return e;
     const bool skip = s.empty_mask != nullptr, d1 = w.traceDepth == 1u;
     // QUEUE builds need the per-wave record queues (DevWork.queue, sized for `queue_blocks` blocks) and exist for the BRICK layout only
-    const bool queue = LAYOUT != LAYOUT_LINEAR && w.fold && w.queue != nullptr && w.pend != nullptr && blocks <= w.queue_blocks;
+    const bool queue = LAYOUT != LAYOUT_LINEAR && w.fold && w.queue != nullptr && w.pend != nullptr && blocks <= w.queue_blocks && w.traceDepth < 32768u;   // a record's bounce counter has 15 bits
 #define SVR_LAUNCH_TILE(SK, D1, QU) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, SK, D1, QU>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2)
     if constexpr (LAYOUT != LAYOUT_LINEAR) {
         if (queue) {
