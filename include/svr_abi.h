@@ -202,11 +202,13 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
                                      majorant-bound fetch culling -- a Woodcock iteration draws its accept number first and
                                      fetches only if it is below (largest alpha reachable in the macro-cell) / sigma_max; bit-identical
                                      results, same random-number stream (csrc/svr_accel.hip, k_bound_class) */
-#define SVR_OPT_PARK_END 19         /* lane machine of the tile kernel (csrc/svr_lanes.hpp): shading / end-of-walk processing runs when this many
-                                     lanes of the wave wait for it (or none can walk); 1..64, default 24.  Speed only */
-#define SVR_OPT_QUEUE 18            /* the tile kernel queues a path at its first scatter event and continues it on a per-lane state machine that
-                                     keeps the 64 lanes of a wave busy (csrc/svr_lanes.hpp): 0 never, 1 (default) for traceDepth >= 4 and for
-                                     media without exactly transparent space, 2 always.  Results identical */
+#define SVR_OPT_PARK_END 19         /* lane machine of the tile kernel at traceDepth > 1 (csrc/svr_lanes.hpp): a round of services (BSDF sampling /
+                                     shading of the waiting paths) runs when this many lanes of the wave could be put to work by it (or none
+                                     walks); 1..64, default 32.  Speed only */
+#define SVR_OPT_QUEUE 18            /* the tile kernel shades the first scatter events of a task in place, queues the paths and continues them on a
+                                     per-lane state machine that keeps the 64 lanes of a wave walking (csrc/svr_lanes.hpp): 0 never, 2 always (on
+                                     folding launches), 1 (default) where it pays: empty-space skipping on and traceDepth >= 2, a medium without
+                                     exactly transparent space, or a launch large enough to drain every wave's queue 4 times.  Results identical */
 #define SVR_OPT_FOLD 17             /* 1 (default): a many-frame launch of the tile kernel folds its frames into the HDR accumulator itself (running
                                      mean in frame order, in the wave that traced them); 0: scratch slot per frame + resolve kernel */
 #define SVR_OPT_FAST_MATH 14        /* OPT-IN, default 0: the tile kernel's fast-math build (v_log_f32 in the walk, reciprocal division, fma contraction;

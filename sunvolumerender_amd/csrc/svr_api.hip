@@ -119,7 +119,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 24, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -565,12 +565,18 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     // pixel per launch, svr_trace_tile.hip); the scratch slots + k_resolve remain for frames traced AHEAD of the calls
     // that ask for them (their radiance is folded later, one frame per call) and for the other kernels.
     const bool fold_batch = cfg.kernel == svr::KERNEL_TILE && g.opt_fold && !g.opt_debug_stop && cfg.frames_log2 < 0;
-    // QUEUE builds (paths continue on a per-lane state machine after their first scatter event, svr_lanes.hpp) pay where what
-    // follows the first event is long and incoherent: media without exactly transparent space (auto: the scenes where bound
-    // culling applies; c3n +33 % at depth 1, +64 % at depth 4) and deep paths (c3: +7 % at depth 4; at depth 1-3 the
-    // straight-line code wins there: the frames of a pixel scatter together, so its shading is already coherent); they ride
-    // on the folding launches
-    const bool use_queue = fold_batch && (g.opt_queue == 2 || (g.opt_queue == 1 && (rp->traceDepth >= 4 || s.bound_cull)));
+    // QUEUE builds (the hits of a task are shaded in place, then their paths continue on a per-lane state machine,
+    // svr_lanes.hpp) ride on the folding launches.  Auto: with empty-space skipping on (without it every walk is long and the
+    // straight-line code wins: c3, 1660 against 1452 Msamples/s), for deep paths and media without exactly transparent space
+    // always (c3 depth 2 / 4: +10 % / +30 %, c3n: +34 %), otherwise when the launch gives every wave at least 4 drains of
+    // QUEUE_TASKS tasks (c3 / c4 / c5: +4 % / +3 % / +12 %; c2, 512^2 pixels: -2 %)
+    bool use_queue = fold_batch && g.opt_queue == 2;
+    if (fold_batch && g.opt_queue == 1 && g.opt_empty_skip) {
+        svr::DevWork wq;
+        fill_work(wq, s.imageW, s.imageH);
+        const uint64_t waves = (uint64_t)(cfg.num_cus * cfg.blocks_per_cu) / 4u * svr::TILE_WAVES;    // blocks of 1024 threads
+        use_queue = rp->traceDepth >= 2 || s.bound_cull || (uint64_t)wq.n_items >= 4u * svr::QUEUE_TASKS * waves;
+    }
     if (use_queue && ensure_record_queues((uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / 16u)) return g.err_code;
     const bool frame_ahead_call = nframes == 1 && g.opt_frame_ahead && g.opt_pipeline && !g.opt_count && !g.opt_debug_stop && cfg.kernel == svr::KERNEL_TILE;
     // short launches (< FOLD_MIN frames) keep the slots: they end in a tail of a few long tasks that only overlapping launches
