@@ -1,23 +1,23 @@
-// svr_lanes.hpp -- everything of a path that follows its FIRST scatter event, as a per-lane state machine over a queue
-// of scatter records (svr_trace_tile.hip, QUEUE builds).
+// svr_lanes.hpp -- what follows the FIRST scatter event of a path: records in the wave's queue memory and a per-lane state
+// machine that drains them (svr_trace_tile.hip, QUEUE builds).
 //
 // Why.  The primary walks of a wave are coherent (its lanes are frames of the same pixels: one shared whole-ray test,
-// similar walk lengths).  What follows a scatter event is not: only some lanes scatter, a shadow walk through a medium
-// that cannot be skipped takes ~10^2 iterations while the other lanes of the wave wait, and after a bounce every lane
-// goes its own way (23 % lane utilisation at traceDepth 4, 17 % in the shadow-walk phase at depth 1:
-// profiles/r01_notes_experiments.txt).  So the wave does not shade its hits in place: a lane that finds its first
-// collision pushes a 14-word RECORD (position, incoming direction, intensity, generator state, path id) onto the wave's
-// queue in global memory -- ballot + mbcnt prefix sum, so the records are dense and the stores coalesce -- and after
-// QUEUE_TASKS tasks (2048 paths: enough records to refill the lanes many times over, so that the tail of the last,
-// longest paths is a small part of a drain) the wave drains the queue with all 64 lanes: every lane runs a state machine
+// similar walk lengths), and so is the shading of their hits.  What follows is not: only some lanes scatter, a shadow
+// walk through a medium that cannot be skipped takes ~10^2 iterations while the other lanes of the wave wait, and after
+// a bounce every lane goes its own way (straight-line code: 32 % lane utilisation at traceDepth 2, 22 % at depth 4).  So
+// the wave shades the hits of a task in place and then hands the paths over:
 //
-//      IDLE -> (pop a record) -> SHADE -> WALK (shadow) -> END -> [bounce: WALK (continuation) -> END -> SHADE ...] -> IDLE
+//   traceDepth 1   record C1 = a shaded event's prepared next-event estimate, waiting for its shadow walk.  After
+//                  QUEUE_TASKS tasks (2048 paths) the wave drains its records with all 64 lanes:
+//                  IDLE -> (pop) -> WALK -> END -> (radiance = estimate x transmittance) -> IDLE
+//   deeper         the first shadow walk and its estimate run in place too; record A = a path waiting for its BSDF
+//                  sampling.  In the machine a lane holds a path only while it WALKs; a finished walk is settled and the
+//                  path waits on the stack of the service it needs -- A (BSDF sampling, throughput, roulette, next walk's
+//                  set-up) or B (shading, light sampling, shadow walk's set-up) -- and a round of services takes all
+//                  non-walking lanes through one of them.
 //
-// in which WALK is the cheap Woodcock iteration of svr_walk.hpp (FREE / EMPTY / CULLED), and everything expensive is a
-// SERVICE the wave runs for the lanes that wait for it: FETCH (8 voxels + filter + LUT), MARCH (whole-ray re-march),
-// SHADE (transfer function, 6 gradient fetches, light sampling, BSDF), END (transmittance -> radiance, BSDF sampling,
-// roulette, next walk's set-up, or the path's end).  A lane that needs a service parks; the wave leaves the iteration
-// loop when enough lanes are parked (or nobody can iterate), serves, refills idle lanes from the queue and goes on.
+// WALK is the cheap Woodcock iteration of svr_walk.hpp (FREE / EMPTY / CULLED); the fetch an iteration asks for (8
+// voxels + filter + LUT) and the re-march after an occupied stretch are served inside the walk loop.
 // All of it is scheduling: each path executes the reference's operations (pathtracer.cu:216-277) in the reference's
 // order on its own generator, so the radiance is bit-identical to the straight-line code of trace_path_tile.
 #pragma once
@@ -186,6 +186,14 @@ SVR_DEV void queue_push_c1(const LaneQueue& Q, uint32_t& nC, bool live, v3 pt, c
     if (live) rec_c1_store(queue_c(Q) + nC + lane_rank(m), Q.cap, pt, ne, rng, id);
     nC += (uint32_t)__popcll(m);
 }
+// deeper, media without exactly transparent space (every walk long, the hits of a task far apart in time): paths at their first
+// scatter event, for the machine to shade
+SVR_DEV void queue_push_b(const LaneQueue& Q, uint32_t& nB, bool live, v3 pt, v3 wo, float val, const Rng& rng, uint32_t id)
+{
+    const uint64_t m = __ballot(live);
+    if (live) rec_b_store(queue_b(Q) + nB + lane_rank(m), Q.cap, pt, wo, val, V3(0.f, 0.f, 0.f), V3(1.f, 1.f, 1.f), rng, rec_meta(id, 0u, 0u, 0));
+    nB += (uint32_t)__popcll(m);
+}
 // deeper: paths after the next-event estimate of their first scatter event
 SVR_DEV void queue_push_a(const LaneQueue& Q, uint32_t& nA, bool live, const Shade& vs, v3 L, const Rng& rng, uint32_t id)
 {
@@ -198,11 +206,11 @@ SVR_DEV void queue_push_a(const LaneQueue& Q, uint32_t& nA, bool live, const Sha
 #define SVR_PARK_CHEAP 16
 #endif
 
-// Drain the wave's records (traceDepth 1: nC shaded first events; deeper: nA paths waiting for the BSDF sampling) with all 64 lanes.  pendL: the
+// Drain the wave's records (traceDepth 1: nC shaded first events; deeper: nA paths waiting for the BSDF sampling, nB0 for the shading) with all 64 lanes.  pendL: the
 // wave's pending-radiance rows ([task * 3 + channel] of pend_row floats); a finished path with id = (task << 6 | lane)
 // stores its radiance at row (id >> 6) * 3 + channel, column id & 63.
 template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS>
-SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, uint32_t nC, uint32_t nA, uint32_t traceDepth_, float* pendL, uint32_t pend_row, Cnt& c,
+SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, uint32_t nC, uint32_t nA, uint32_t nB0, uint32_t traceDepth_, float* pendL, uint32_t pend_row, Cnt& c,
                          unsigned long long* c_prof = nullptr)
 {
     enum : uint32_t { IDLE = 0u, WALK = 2u, FETCH = 3u, MARCH = 4u, END = 5u, WANT_A = 6u, WANT_B = 7u };
@@ -347,7 +355,7 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
         // was triggered on its own count, and 15 of 64 lanes walked on average (c3, traceDepth 4).  So waiting paths go
         // to memory instead -- one stack per service -- and a round of services takes ALL non-walking lanes through the
         // service with more paths waiting (lanes that already hold such a path keep it, the rest push theirs and pop).
-        uint32_t nB = 0u;
+        uint32_t nB = nB0;
         uint32_t* const qa = queue_a(Q);
         uint32_t* const qb = queue_b(Q);
         // after the next-event estimate of bounce k (pathtracer.cu:258-276): the next direction, the throughput, roulette,

@@ -149,7 +149,7 @@ SVR_DEV v3 trace_path_tile(const DevScene& s, const LDS& L_, uint32_t x, uint32_
 }
 
 // The part of a path up to its first scatter event (k = 0 of kernel_pathtracer's loop, pathtracer.cu:205-235) for QUEUE
-// builds: returns true if the primary walk collided -- pt / wo / val / rng are then what a scatter record holds and
+// builds: returns true if the primary walk collided -- pt / wo / val / rng are then the scatter event the wave shades in place and
 // svr_lanes.hpp continues the path -- and false if the path is over, with its radiance in L.
 template <int LAYOUT, bool COUNT, bool SKIP, typename LDS>
 SVR_DEV bool trace_primary(const DevScene& s, const LDS& L_, uint32_t x, uint32_t y, uint32_t hashed, bool group_march, uint32_t P2,
@@ -207,7 +207,7 @@ SVR_DEV bool trace_primary(const DevScene& s, const LDS& L_, uint32_t x, uint32_
 constexpr uint32_t PEND_TASKS = 4;
 constexpr uint32_t PEND_ROW = 65;
 // QUEUE builds keep the radiance of the last QUEUE_TASKS tasks in a per-wave buffer in global memory instead (rows of 64
-// floats; written and read back by the same CU, so it lives in L2), and up to QUEUE_CAP scatter records per wave
+// floats; written and read back once by the same wave), and up to QUEUE_CAP path records per wave
 // (QUEUE_TASKS = 32 and QUEUE_CAP = 1024: svr_kernels.hpp, shared with the allocation in svr_api.hip)
 static_assert(TILE_WAVES == SVR_TILE_THREADS / 64, "svr_kernels.hpp sizes the queues for 16 waves per block");
 struct LdsPend {
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
     const uint32_t n_units = (n_tasks + unit - 1u) / unit;
     const uint32_t shard0 = blockIdx.x % TICKET_SHARDS;
     const bool fold = w.fold != 0u;                               // host guarantees fgroups == 1 then
-    uint32_t npend = 0, qC = 0, qA = 0;
+    uint32_t npend = 0, qC = 0, qA = 0, qB = 0;
     LaneQueue Q;
     Q.cap = QUEUE_CAP;
     Q.q = QUEUE ? w.queue + (size_t)(blockIdx.x * TILE_WAVES + wave) * (REC_WORDS * QUEUE_CAP) : nullptr;
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
         if constexpr (QUEUE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // records and radiance are read back by other lanes of this wave
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, Q, qC, qA, w.traceDepth, gpend, 64u, c, w.counters + CNT_N);
-            qC = qA = 0;
+            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, Q, qC, qA, qB, w.traceDepth, gpend, 64u, c, w.counters + CNT_N);
+            qC = qA = qB = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #if SVR_PROF
@@ -391,14 +391,30 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                     unsigned long long* c_prof = w.counters + CNT_N;
 #endif
                     PROF_BEGIN(pa, PH_PRIMARY);
+#if SVR_PROF
+                    const uint32_t prof_i0 = c.iters - c.iskip;
+#endif
                     if (live) {
                         uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
                         hit = trace_primary<LAYOUT, COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, vs.pt, vs.wo, val);
                     }
                     PROF_END(pa, (uint32_t)__popcll(__ballot(live)));
+#if SVR_PROF
+                    if (COUNT && DEPTH1) {
+                        // counting experiment builds: executed iterations of the primary walks, and 64 x the longest of the wave
+                        const uint32_t d = (c.iters - c.iskip) - prof_i0;
+                        uint32_t m = d;
+                        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+                        const unsigned long long sum = wave_sum(d);
+                        if (lane == 0) { atomicAdd(&c_prof[2 * PH_N], (unsigned long long)m * 64ull); atomicAdd(&c_prof[2 * PH_N + 1], sum); }
+                    }
+#endif
+                    // (deeper paths through a medium without exactly transparent space are queued unshaded: every walk is long
+                    // there and the hits of a task lie far apart in time; c3n depth 4: 606 against 558 Msamples/s)
+                    const bool shade_here = DEPTH1 || !s.bound_cull;
                     {
                         const uint64_t mh = __ballot(hit);
-                        if (mh != 0ull) {
+                        if (shade_here && mh != 0ull) {
                             PROF_BEGIN(psh, PH_SHADE);
                             if (hit) {
                                 shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
@@ -423,7 +439,8 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                         queue_push_c1(Q, qC, hit && ne.have, vs.pt, ne, rng, (npend << 6) | lane);
                         over = !(hit && ne.have);                     // the camera ray's radiance, or a first event no light sample reaches (L = 0)
                     } else {
-                        queue_push_a(Q, qA, hit, vs, L, rng, (npend << 6) | lane);
+                        if (shade_here) queue_push_a(Q, qA, hit, vs, L, rng, (npend << 6) | lane);
+                        else queue_push_b(Q, qB, hit, vs.pt, vs.wo, val, rng, (npend << 6) | lane);
                         over = !hit;
                     }
                     if (over) {
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                         o[0] = L.x; o[64] = L.y; o[128] = L.z;
                     }
                     if (lane == 0) pend.task[wave][npend] = k;
-                    if (++npend == QUEUE_TASKS || qC + qA + 64u > QUEUE_CAP) flush();
+                    if (++npend == QUEUE_TASKS || qC + qA + qB + 64u > QUEUE_CAP) flush();
                     continue;
                 } else {
                     v3 L = V3(0.f, 0.f, 0.f);

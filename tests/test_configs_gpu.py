@@ -12,6 +12,8 @@ The oracle runs on SVR_CPU_THREADS host threads (default 16 = one GPU's CPU shar
 import ctypes as C
 import os
 
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -172,6 +174,25 @@ def test_c3n_culling_and_queue_equal_plain_walks_full_frame(hip_dev):
             o.render_pathtracer(ref, f, window=w, count=False, nthreads=THREADS)
         x0, y0, x1, y1 = w
         assert_bit_exact(a[y0:y1, x0:x1], ref[y0:y1, x0:x1], "c3n vs oracle")
+        # deeper paths through this medium are queued at their first scatter event, unshaded (svr_trace_tile.hip): depth 3,
+        # 16-frame launch, defaults against plain walks on the whole frame, and a window against the oracle
+        hip_dev.set_option(abi.OPT_QUEUE, 1)
+        hip_dev.set_option(abi.OPT_BOUND_CULL, 1)
+        r.canvas.SetScatterTimes(3)
+        sc3 = dataclasses.replace(r.sc, trace_depth=3)
+        a3, a3i, _ = r.run(16)
+        hip_dev.set_option(abi.OPT_QUEUE, 0)
+        hip_dev.set_option(abi.OPT_BOUND_CULL, 0)
+        b3, b3i, _ = r.run(16)
+        assert_bit_exact(a3, b3, "c3n depth 3: culling + queue machine vs plain walks, full frame")
+        assert np.array_equal(a3i, b3i)
+        o3 = binding.OracleScene(sc3)
+        ref3 = o3.new_hdr()
+        w3 = (496, 502, 528, 506)
+        for f in range(16):
+            o3.render_pathtracer(ref3, f, window=w3, count=False, nthreads=THREADS)
+        x0, y0, x1, y1 = w3
+        assert_bit_exact(a3[y0:y1, x0:x1], ref3[y0:y1, x0:x1], "c3n depth 3 vs oracle")
     finally:
         hip_dev.set_option(abi.OPT_QUEUE, 1)
         hip_dev.set_option(abi.OPT_BOUND_CULL, 1)

@@ -35,5 +35,8 @@ for setting in a.settings:
         if cyc:
             print(f"   {n:8s} {cyc / tot * 100:6.2f} %   util {lc / cyc / 64 * 100:5.1f} %")
     if out[16]:
-        print(f"   cheap-loop iterations {int(out[16])}, mean walking lanes {float(out[17]) / float(out[16]):.1f}")
+        if a.depth > 1:
+            print(f"   cheap-loop iterations {int(out[16])}, mean walking lanes {float(out[17]) / float(out[16]):.1f}")
+        else:
+            print(f"   primary walks (count=1 only): executed lane-iterations / (64 x longest walk of the wave) = {float(out[17]) / float(out[16]):.3f}")
 c.close()
