@@ -23,7 +23,8 @@ One JSON line on rank 0 (the task contract's fields) plus
                 taps are proven transparent and never fetched, so `algorithmic_demand_frac` can exceed 1 and is not a
                 fraction of anything -- `hbm_traffic_bytes` is what HBM really moved.
   workloads     the same measurement on the scenes where nothing can be skipped and algorithmic bytes = executed
-                bytes: c3 with noisy, non-zero air (`c3n`), and c3 with empty-space skipping switched off.
+                bytes: c3 with noisy, non-zero air (`c3n`), and c3 with empty-space skipping switched off; the headline
+                scene in the opt-in fast-math mode, and at trace depth 2 and 4.
   cpu_baseline  the CPU oracle (a plain-C port of the reference's arithmetic, OpenMP) on a bounded sample.
 """
 from __future__ import annotations
@@ -62,7 +63,7 @@ def parse_args():
     ap.add_argument("--assemble", default="gather", choices=["gather", "reduce"], help="collective that assembles the frame on rank 0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget (0 = skip)")
     ap.add_argument("--no-count", action="store_true", help="skip the tap-counting pass (algorithmic_* = null)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (noisy air, skipping off)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (noisy air, skipping off, fast math, depth 2 / 4)")
     ap.add_argument("--extra-steps", type=int, default=2)
     ap.add_argument("--empty-skip", type=int, default=1)
     ap.add_argument("--fast-math", type=int, default=0)
@@ -386,11 +387,21 @@ def main():
         extra = {}
         # (the C ABI holds ONE scene per process, like the reference's __constant__ globals: the headline canvas goes
         # first, the second canvas replaces the scene and nothing is rendered on the first one afterwards)
-        for tag, sc_name, skip in (("c3_skip_off", "c3", 0), ("c3_noisy_air", "c3n", 1)):
+        # (tag, scene, empty-skip, fast math, trace depth, what it is)
+        plan = [("c3_skip_off", "c3", 0, 0, args.trace_depth, "the headline scene with SVR_OPT_EMPTY_SKIP = 0: every tap of the reference algorithm is fetched"),
+                ("c3_fast_math", "c3", 1, 1, args.trace_depth, "the headline scene in the OPT-IN fast-math mode (SVR_OPT_FAST_MATH: v_log / reciprocal division / "
+                                                              "contraction; not bit-identical, converged images agree within Monte-Carlo noise)")]
+        if args.trace_depth == 1 and not args.fast_math:
+            plan += [(f"c3_depth{d}", "c3", 1, 0, d, f"the headline scene at trace depth {d} (the reference's GUI range is 1-10)") for d in (2, 4)]
+        plan += [("c3_noisy_air", "c3n", 1, 0, args.trace_depth, "c3 with noisy non-zero air (64..191 raw LSB, like CT data rescaled to the full u16 range): no "
+                                                                 "macro-cell is exactly transparent")]
+        for tag, sc_name, skip, fast, depth, what in plan:
             w2 = wl if sc_name == args.scene else Workload(dev, torch, sc_name, args.trace_depth, args.layout)
             dev.set_option(abi.OPT_EMPTY_SKIP, skip)
+            dev.set_option(abi.OPT_FAST_MATH, fast)
+            w2.canvas.SetScatterTimes(depth)
             n = max(1, args.extra_steps)
-            c2 = None if args.no_count else w2.count(n, S)
+            c2 = None if (args.no_count or fast) else w2.count(n, S)
             w2.canvas.ReStartRender()
             w2.step(S)
             w2.canvas.ReStartRender()
@@ -404,14 +415,12 @@ def main():
             dt = time.perf_counter() - t1
             dev.set_option(abi.OPT_TIMING, 0)
             ms2, n2 = dev.kernel_time()
-            r2 = roofline_block(c2, S, n, ms2, n2, pmc_record(f"{sc_name}_d{args.trace_depth}" + ("" if skip else "_noskip")))
+            r2 = roofline_block(c2, S, n, ms2, n2, None if fast else pmc_record(f"{sc_name}_d{depth}" + ("" if skip else "_noskip")))
             extra[tag] = {"value": round(float(W) * H * S * n / dt / 1e6, 3), "unit": "Msamples/s", "steps": n,
-                          "ms_per_step": round(dt / n * 1e3, 3),
-                          "what": ("c3 with noisy non-zero air (64..191 raw LSB, like CT data rescaled to the full u16 range): no "
-                                   "macro-cell is exactly transparent" if sc_name == "c3n" else
-                                   "the headline scene with SVR_OPT_EMPTY_SKIP = 0: every tap of the reference algorithm is fetched"),
-                          "roofline": r2}
+                          "ms_per_step": round(dt / n * 1e3, 3), "trace_depth": depth, "what": what, "roofline": r2}
             dev.set_option(abi.OPT_EMPTY_SKIP, args.empty_skip)
+            dev.set_option(abi.OPT_FAST_MATH, args.fast_math)
+            w2.canvas.SetScatterTimes(args.trace_depth)
             if w2 is not wl:
                 w2.close()
         out["workloads"] = extra
