@@ -86,6 +86,7 @@ struct Context {
     uint32_t* d_queue = nullptr;        // scatter-record queues of the tile kernel's folding launches (they run one at a time)
     float* d_pend = nullptr;            // ... and the waves' pending-radiance rows
     uint32_t queue_blocks = 0;          // blocks both are sized for
+    bool queue_alloc_failed = false;    // SVR_OPT_QUEUE = 1 and the device had no room for them: straight-line launches
     hipEvent_t prev_traced = nullptr;   // `traced` event of the latest trace launch (owned by its set)
     // frames traced ahead of the host's render_pathtracer calls (render_frames)
     struct Ahead {
@@ -499,19 +500,34 @@ int ensure_slots(uint32_t W, uint32_t H, uint32_t nslots)
     return 0;
 }
 
-// per-wave scatter-record queues (REC_WORDS x QUEUE_CAP words) and pending-radiance rows (QUEUE_TASKS x 3 x 64 floats) of the
-// tile kernel's QUEUE builds (svr_trace_tile.hip, svr_lanes.hpp): 57 KB + 24 KB per wave, 330 MB for 256 blocks
+// per-wave path-record queues (REC_WORDS x QUEUE_CAP words) and pending-radiance rows (QUEUE_TASKS x 3 x 64 floats) of the
+// tile kernel's QUEUE builds (svr_trace_tile.hip, svr_lanes.hpp): 184 KB + 24 KB per wave, 0.85 GB for 256 blocks.
+// soft: the caller can do without them (SVR_OPT_QUEUE = 1): running out of device memory is then not an error, the launches
+// use the straight-line kernel and the allocation is not tried again until the option is set anew.
 using svr::QUEUE_WORDS_PER_BLOCK;
 using svr::PEND_FLOATS_PER_BLOCK;
-int ensure_record_queues(uint32_t blocks)
+int ensure_record_queues(uint32_t blocks, bool soft, bool& available)
 {
-    if (g.d_queue && g.queue_blocks >= blocks) return 0;
+    available = true;
+    if (g.d_queue && g.d_pend && g.queue_blocks >= blocks) return 0;
+    if (soft && g.queue_alloc_failed) { available = false; return 0; }
     HIP_TRY(hipDeviceSynchronize());
     if (g.d_queue) { HIP_TRY(hipFree(g.d_queue)); g.d_queue = nullptr; }
     if (g.d_pend) { HIP_TRY(hipFree(g.d_pend)); g.d_pend = nullptr; }
     g.queue_blocks = 0;
-    HIP_TRY(hipMalloc((void**)&g.d_queue, QUEUE_WORDS_PER_BLOCK * sizeof(uint32_t) * blocks));
-    HIP_TRY(hipMalloc((void**)&g.d_pend, PEND_FLOATS_PER_BLOCK * sizeof(float) * blocks));
+    hipError_t e = hipMalloc((void**)&g.d_queue, QUEUE_WORDS_PER_BLOCK * sizeof(uint32_t) * blocks);
+    if (e == hipSuccess) e = hipMalloc((void**)&g.d_pend, PEND_FLOATS_PER_BLOCK * sizeof(float) * blocks);
+    if (e != hipSuccess) {
+        if (g.d_queue) { (void)hipFree(g.d_queue); g.d_queue = nullptr; }
+        g.d_pend = nullptr;
+        if (soft && e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            g.queue_alloc_failed = true;
+            available = false;
+            return 0;
+        }
+        return fail((int)e, "HIP error allocating the tile kernel's queue memory (%zu MB): %s", ((QUEUE_WORDS_PER_BLOCK + PEND_FLOATS_PER_BLOCK) * 4 * blocks) >> 20, hipGetErrorName(e));
+    }
     g.queue_blocks = blocks;
     return 0;
 }
@@ -577,7 +593,11 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         const uint64_t waves = (uint64_t)(cfg.num_cus * cfg.blocks_per_cu) / 4u * svr::TILE_WAVES;    // blocks of 1024 threads
         use_queue = rp->traceDepth >= 2 || s.bound_cull || (uint64_t)wq.n_items >= 4u * svr::QUEUE_TASKS * waves;
     }
-    if (use_queue && ensure_record_queues((uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / 16u)) return g.err_code;
+    if (use_queue) {
+        bool available = true;
+        if (ensure_record_queues((uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / 16u, g.opt_queue == 1, available)) return g.err_code;
+        use_queue = available;
+    }
     const bool frame_ahead_call = nframes == 1 && g.opt_frame_ahead && g.opt_pipeline && !g.opt_count && !g.opt_debug_stop && cfg.kernel == svr::KERNEL_TILE;
     // short launches (< FOLD_MIN frames) keep the slots: they end in a tail of a few long tasks that only overlapping launches
     // on several streams hide, and a folding launch cannot overlap its predecessor (measured, 1 frame per call: 0.276 vs 0.366 ms)
@@ -1148,7 +1168,7 @@ int svr_set_option(int key, int value)
     case SVR_OPT_FAST_MATH: g.opt_fast_math = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_QUEUE:
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_QUEUE: bad value %d (0 off, 1 auto, 2 always)", value);
-        g.opt_queue = value; return 0;
+        g.opt_queue = value; g.queue_alloc_failed = false; return 0;
     case SVR_OPT_PARK_END:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_END: bad value %d (1..64)", value);
         g.opt_park_end = value; return 0;
