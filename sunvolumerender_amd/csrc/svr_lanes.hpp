@@ -205,6 +205,12 @@ SVR_DEV void queue_push_a(const LaneQueue& Q, uint32_t& nA, bool live, const Sha
 #ifndef SVR_PARK_CHEAP
 #define SVR_PARK_CHEAP 16
 #endif
+#ifndef SVR_FREE_MIN
+#define SVR_FREE_MIN 16      // deeper paths: lanes in fetch-free iterations that make a loop of their own worthwhile ...
+#endif
+#ifndef SVR_FREE_ROUNDS
+#define SVR_FREE_ROUNDS 8    // ... and its rounds per turn
+#endif
 
 // Drain the wave's records (traceDepth 1: nC shaded first events; deeper: nA paths waiting for the BSDF sampling, nB0 for the shading) with all 64 lanes.  pendL: the
 // wave's pending-radiance rows ([task * 3 + channel] of pend_row floats); a finished path with id = (task << 6 | lane)
@@ -213,7 +219,7 @@ template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS>
 SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, uint32_t nC, uint32_t nA, uint32_t nB0, uint32_t traceDepth_, float* pendL, uint32_t pend_row, Cnt& c,
                          unsigned long long* c_prof = nullptr)
 {
-    enum : uint32_t { IDLE = 0u, WALK = 2u, FETCH = 3u, MARCH = 4u, END = 5u, WANT_A = 6u, WANT_B = 7u };
+    enum : uint32_t { IDLE = 0u, CELL = 1u, WALK = 2u, FETCH = 3u, MARCH = 4u, END = 5u, WANT_A = 6u, WANT_B = 7u };
     const float INF = u2f(SVR_INF_BITS);
     const uint32_t traceDepth = DEPTH1 ? 1u : traceDepth_;
     uint32_t st = IDLE;
@@ -245,15 +251,18 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
     // one Woodcock iteration of a walking lane without a fetch (woodcock_tracking.h:32-45): FREE / EMPTY / CULLED keep it
     // in WALK, anything else parks it (FETCH, MARCH) or ends the walk (END)
     auto iterate = [&]() {
-        if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; }
-        t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-        if (t > tMax || guard++ >= SVR_WALK_GUARD) { st = END; return; }
-        if (COUNT) c.taps++;
-        if (SKIP && t < t_occ) {
-            if (COUNT && !(ray_skippable || tail_counted)) c.ipre++;
-            rng_skip(rng);                                  // the accept draw of a FREE iteration
-            return;
+        if (st != CELL) {
+            if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; }
+            t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+            if (t > tMax || guard++ >= SVR_WALK_GUARD) { st = END; return; }
+            if (COUNT) c.taps++;
+            if (SKIP && t < t_occ) {
+                if (COUNT && !(ray_skippable || tail_counted)) c.ipre++;
+                rng_skip(rng);                                  // the accept draw of a FREE iteration
+                return;
+            }
         }
+        st = WALK;
         const Cell cell = cell_of(s, orig + dir * t);
         CellInfo ci;
         ci.empty = false; ci.deep = false; ci.thr = INF;
@@ -268,6 +277,20 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
             if (xi < ci.thr) st = FETCH;                   // else CULLED: xi >= bound >= sigma_t * invSigmaMax
             else if (COUNT) c.cull++;
         }
+    };
+    // the same iteration for a lane that is before its first possibly-occupied cell (t < t_occ), without the rest: the lane
+    // stays such a lane, ends its walk, or stops with the iteration's cell test pending (CELL)
+    auto free_iterate = [&]() {
+        if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; }
+        t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+        if (t > tMax || guard++ >= SVR_WALK_GUARD) { st = END; return; }
+        if (COUNT) c.taps++;
+        if (t < t_occ) {
+            if (COUNT && !(ray_skippable || tail_counted)) c.ipre++;
+            rng_skip(rng);
+            return;
+        }
+        st = CELL;
     };
 
     // the services of a walking lane that cannot wait: the fetch an iteration asked for, the re-march after an occupied stretch
@@ -443,14 +466,22 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
 #if SVR_PROF
             uint32_t pc_it = 0u, pc_walk = 0u;
 #endif
-            while (__ballot(st == WALK) != 0ull) {
+            while (__ballot(st == WALK || st == CELL) != 0ull) {
                 // lanes a round of services could put to work
                 const uint32_t n_end = (uint32_t)__popcll(__ballot(st == END)), n_idle = (uint32_t)__popcll(__ballot(st == IDLE));
                 if (n_end + min(n_idle, nA + nB) >= park_end) break;
 #if SVR_PROF
                 pc_it++; pc_walk += (uint32_t)__popcll(__ballot(st == WALK));
 #endif
-                if (st == WALK) iterate();
+                // A turn pays for the cell tests, fetches and re-marches of whichever lanes need them.  While most lanes are between
+                // occupied stretches (or behind the last one, consuming the draws a later sample needs), they run their ~50-instruction
+                // fetch-free iterations in a loop of their own, a few rounds at a time
+                if (SKIP) {
+#pragma nounroll
+                    for (uint32_t rounds = 0u; rounds < SVR_FREE_ROUNDS && (uint32_t)__popcll(__ballot(st == WALK && t < t_occ)) >= SVR_FREE_MIN; ++rounds)
+                        if (st == WALK && t < t_occ) free_iterate();
+                }
+                if (st == WALK || st == CELL) iterate();
                 serve_fetch_march();
             }
 #if SVR_PROF
@@ -479,16 +510,16 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
             const uint32_t cA = nA + (uint32_t)__popcll(__ballot(st == WANT_A));
             const uint32_t cB = nB + (uint32_t)__popcll(__ballot(st == WANT_B));
             if (cA + cB == 0u) {
-                if (__ballot(st == WALK) == 0ull) break;                 // no walk, no waiting path, no record: the queue is drained
+                if (__ballot(st == WALK || st == CELL) == 0ull) break;   // no walk, no waiting path, no record: the queue is drained
                 continue;
             }
             if (cB >= cA) {
                 push_a(); pop_b(); serve_b();
                 // the other service, for the lanes still idle, if they are many or nothing else can run
-                if (nA != 0u && ((uint32_t)__popcll(__ballot(st == IDLE)) >= park_end || __ballot(st == WALK) == 0ull)) { pop_a(); serve_a(); }
+                if (nA != 0u && ((uint32_t)__popcll(__ballot(st == IDLE)) >= park_end || __ballot(st == WALK || st == CELL) == 0ull)) { pop_a(); serve_a(); }
             } else {
                 push_b(); pop_a(); serve_a();
-                if (nB != 0u && ((uint32_t)__popcll(__ballot(st == IDLE)) >= park_end || __ballot(st == WALK) == 0ull)) { pop_b(); serve_b(); }
+                if (nB != 0u && ((uint32_t)__popcll(__ballot(st == IDLE)) >= park_end || __ballot(st == WALK || st == CELL) == 0ull)) { pop_b(); serve_b(); }
             }
         }
     }
