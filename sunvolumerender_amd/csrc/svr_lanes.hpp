@@ -208,6 +208,9 @@ SVR_DEV void queue_push_a(const LaneQueue& Q, uint32_t& nA, bool live, const Sha
 #ifndef SVR_FREE_MIN
 #define SVR_FREE_MIN 16      // deeper paths: lanes in fetch-free iterations that make a loop of their own worthwhile ...
 #endif
+#ifndef SVR_FREE_MIN_D1
+#define SVR_FREE_MIN_D1 32   // the same at traceDepth 1 (rarely met there: walks without a live generator end behind their last occupied stretch)
+#endif
 #ifndef SVR_FREE_ROUNDS
 #define SVR_FREE_ROUNDS 8    // ... and its rounds per turn
 #endif
@@ -348,9 +351,14 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
         uint32_t next = 0u;
         for (;;) {
             PROF_BEGIN(pw, PH_CHEAP);
-            while (__ballot(st == WALK) != 0ull) {
+            while (__ballot(st == WALK || st == CELL) != 0ull) {
                 if ((uint32_t)__popcll(__ballot(st == END)) + min((uint32_t)__popcll(__ballot(st == IDLE)), nC - next) >= park_cheap) break;
-                if (st == WALK) iterate();
+                if (SKIP) {
+#pragma nounroll
+                    for (uint32_t rounds = 0u; rounds < SVR_FREE_ROUNDS && (uint32_t)__popcll(__ballot(st == WALK && t < t_occ)) >= SVR_FREE_MIN_D1; ++rounds)
+                        if (st == WALK && t < t_occ) free_iterate();
+                }
+                if (st == WALK || st == CELL) iterate();
                 serve_fetch_march();
             }
             PROF_END(pw, 32u);
