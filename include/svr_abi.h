@@ -220,6 +220,11 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
 #define SVR_OPT_ROW_ORDER 21        /* tile kernel work distribution: 1 = each of the 8 ticket counters (one per XCD group of blocks) owns whole tile
                                      rows, so neighbouring tiles share an XCD's L2; 0 = every 8th task.  Speed only */
 #define SVR_OPT_GROUP_FRAMES 22     /* frames per folding launch of svr_render_pathtracer_frames: 8, 16, 32 or 64 (default: a wave = one pixel x 64 frames).  Speed only */
+#define SVR_OPT_LOCAL_MAJORANT 23   /* OPT-IN, default 0: "Woodcock max-density acceleration" -- the free-flight sampler tracks against per-macro-cell
+                                     * (local) majorants instead of the reference's single global one (core/woodcock_tracking.h:29-31): same law of the
+                                     * collision point, far fewer iterations, but a different consumption of random numbers.  NOT bit-identical to
+                                     * the default mode; converged images agree within Monte-Carlo noise (tests/test_local_majorant_gpu.py).  Needs
+                                     * SVR_OPT_EMPTY_SKIP = 1 and clip planes inside the volume; otherwise the default kernel renders */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */

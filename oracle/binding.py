@@ -61,6 +61,7 @@ def build(force: bool = False) -> Path:
         subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "libsvr_oracle.so"], check=True, capture_output=True)
     build_ref(force)
     build_fresnel_ref(force)
+    build_wanghash_ref(force)
     return LIB
 
 
@@ -97,6 +98,29 @@ def build_fresnel_ref(force: bool = False):
             force or not FRESNEL_REF.exists() or FRESNEL_REF.stat().st_mtime < (ORACLE_DIR / "ref_fresnel.cpp").stat().st_mtime):
         subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "_ref/libref_fresnel.so", f"CUDA_INC={inc}"], check=True, capture_output=True)
     return FRESNEL_REF if FRESNEL_REF.exists() else None
+
+
+WANGHASH_REF = ORACLE_DIR / "_ref" / "libref_wanghash.so"
+
+
+def build_wanghash_ref(force: bool = False):
+    """oracle/_ref/libref_wanghash.so: the reference's own wangHash (pathtracer.cu:70-79), cut out of the file where it lies at
+    build time (oracle/ref_wanghash.cpp, oracle/Makefile)."""
+    inc = _cuda_include_dir()
+    if (REFERENCE / "pathtracer.cu").exists() and inc is not None and (
+            force or not WANGHASH_REF.exists() or WANGHASH_REF.stat().st_mtime < (ORACLE_DIR / "ref_wanghash.cpp").stat().st_mtime):
+        subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "_ref/libref_wanghash.so", f"CUDA_INC={inc}"], check=True, capture_output=True)
+    return WANGHASH_REF if WANGHASH_REF.exists() else None
+
+
+def wanghash_ref():
+    path = build_wanghash_ref()
+    if path is None:
+        return None
+    lib = C.CDLL(str(path))
+    lib.ref_wang_hash.restype = C.c_uint32
+    lib.ref_wang_hash.argtypes = [C.c_uint32]
+    return lib
 
 
 def fresnel_ref():

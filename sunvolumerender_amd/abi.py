@@ -143,6 +143,7 @@ OPT_PARK_END = 19
 OPT_FINE_MASK = 20
 OPT_ROW_ORDER = 21
 OPT_GROUP_FRAMES = 22
+OPT_LOCAL_MAJORANT = 23
 KERNEL_AUTO, KERNEL_PIXEL, KERNEL_TILE, KERNEL_ULOOP, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4
 
 ELEM_I8, ELEM_U8, ELEM_I16, ELEM_U16, ELEM_I32, ELEM_U32, ELEM_F32, ELEM_F64 = range(8)

@@ -120,7 +120,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -593,11 +593,19 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         const uint64_t waves = (uint64_t)(cfg.num_cus * cfg.blocks_per_cu) / 4u * svr::TILE_WAVES;    // blocks of 1024 threads
         use_queue = rp->traceDepth >= 2 || s.bound_cull || (uint64_t)wq.n_items >= 4u * svr::QUEUE_TASKS * waves;
     }
-    if (use_queue) {
+    // OPT-IN local majorants (svr_trace_lm.hip): needs the class table and whole-ray validity; its folding launches keep the waves'
+    // pending radiance in the rows next to the record queues
+    const bool local_majorant = g.opt_local_majorant && cfg.kernel == svr::KERNEL_TILE && s.empty_mask != nullptr && s.ray_skip && !g.opt_debug_stop;
+    if (local_majorant) use_queue = false;
+    if (use_queue || (local_majorant && fold_batch)) {
         bool available = true;
-        if (ensure_record_queues((uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / 16u, g.opt_queue == 1, available)) return g.err_code;
-        use_queue = available;
+        if (ensure_record_queues((uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / 16u, g.opt_queue == 1 && !local_majorant, available)) return g.err_code;
+        use_queue = use_queue && available;
     }
+    auto launch_tile = [&](const svr::DevWork& w, hipStream_t st) -> hipError_t {
+        if (local_majorant) return svr::launch_trace_lm(s, w, cfg, st);
+        return g.opt_fast_math ? svr_fast::launch_trace_tile_raw(&s, &w, &cfg, st) : svr::launch_trace_tile(s, w, cfg, st);
+    };
     const bool frame_ahead_call = nframes == 1 && g.opt_frame_ahead && g.opt_pipeline && !g.opt_count && !g.opt_debug_stop && cfg.kernel == svr::KERNEL_TILE;
     // short launches (< FOLD_MIN frames) keep the slots: they end in a tail of a few long tasks that only overlapping launches
     // on several streams hide, and a folding launch cannot overlap its predecessor (measured, 1 frame per call: 0.276 vs 0.366 ms)
@@ -618,7 +626,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         w.nframes = n;
         w.fold = 1u;
         w.queue = use_queue ? g.d_queue : nullptr;
-        w.pend = use_queue ? g.d_pend : nullptr;
+        w.pend = (use_queue || local_majorant) ? g.d_pend : nullptr;
         w.queue_blocks = g.queue_blocks;
         int slot = -1;
         if (g.opt_timing) {
@@ -626,7 +634,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
             slot = g.ev_head;
             HIP_TRY(hipEventRecord(g.ev0[slot], g.stream));
         }
-        HIP_TRY(g.opt_fast_math ? svr_fast::launch_trace_tile_raw(&s, &w, &cfg, g.stream) : svr::launch_trace_tile(s, w, cfg, g.stream));
+        HIP_TRY(launch_tile(w, g.stream));
         if (g.opt_timing) {
             HIP_TRY(hipEventRecord(g.ev1[slot], g.stream));
             g.ev_head = (g.ev_head + 1) % Context::EV_RING;
@@ -667,7 +675,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         }
         if (cfg.kernel == svr::KERNEL_WAVEFRONT)
             HIP_TRY(svr::launch_wavefront(s, w, cfg, set.planes, set.wf_counts, (uint32_t)g.queue_capacity, ts));
-        else if (cfg.kernel == svr::KERNEL_TILE) HIP_TRY(g.opt_fast_math ? svr_fast::launch_trace_tile_raw(&s, &w, &cfg, ts) : svr::launch_trace_tile(s, w, cfg, ts));
+        else if (cfg.kernel == svr::KERNEL_TILE) HIP_TRY(launch_tile(w, ts));
         else HIP_TRY(svr::launch_pathtrace(s, w, cfg, ts));
         if (g.opt_timing) {
             HIP_TRY(hipEventRecord(g.ev1[slot], ts));
@@ -1166,6 +1174,7 @@ int svr_set_option(int key, int value)
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_FINE_MASK: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_fine_mask = value; return 0;
     case SVR_OPT_FAST_MATH: g.opt_fast_math = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
+    case SVR_OPT_LOCAL_MAJORANT: g.opt_local_majorant = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_QUEUE:
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_QUEUE: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_queue = value; g.queue_alloc_failed = false; return 0;
@@ -1209,6 +1218,7 @@ int svr_get_option(int key)
     case SVR_OPT_ROW_ORDER: return g.opt_row_order;
     case SVR_OPT_FINE_MASK: return g.opt_fine_mask;
     case SVR_OPT_FAST_MATH: return g.opt_fast_math;
+    case SVR_OPT_LOCAL_MAJORANT: return g.opt_local_majorant;
     case SVR_OPT_QUEUE: return g.opt_queue;
     case SVR_OPT_PARK_END: return g.opt_park_end;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;

@@ -28,6 +28,9 @@ SVR_DEV void rng_init(Rng& r, uint32_t seed)
     r.v4 = 5783321u + t0;
 }
 
+// curand_uniform's mapping of the draw's integer x = v4 + d
+SVR_DEV float rng_to_uniform(uint32_t x) { return (float)x * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
+
 SVR_DEV float rng_uniform(Rng& r)
 {
     uint32_t t = r.v0 ^ (r.v0 >> 2);
@@ -37,8 +40,7 @@ SVR_DEV float rng_uniform(Rng& r)
     r.v3 = r.v4;
     r.v4 = (r.v4 ^ (r.v4 << 4)) ^ (t ^ (t << 1));
     r.d += 362437u;
-    uint32_t x = r.v4 + r.d;
-    return (float)x * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
+    return rng_to_uniform(r.v4 + r.d);
 }
 
 // advance the generator by one draw whose value is not needed
@@ -52,6 +54,41 @@ SVR_DEV void rng_skip(Rng& r)
     r.v4 = (r.v4 ^ (r.v4 << 4)) ^ (t ^ (t << 1));
     r.d += 362437u;
 }
+
+// The same generator as a CIRCULAR BUFFER with a compile-time head H: logical v_i = word (H + i) % 5.  A step overwrites
+// the word that falls out of the recurrence (logical v0) with the new v4 and the head moves on, instead of shifting the
+// other four words: no register moves.  Loops that hold k steps per iteration unroll 5 / gcd(5, k) times with
+// H = 0, k, 2k ... (mod 5), after which the buffer is where it started; an exit in between records its head for rng_canon.
+template <int H> SVR_DEV uint32_t& rng_word(Rng& r)
+{
+    static_assert(H >= 0 && H < 5, "head");
+    if constexpr (H == 0) return r.v0;
+    else if constexpr (H == 1) return r.v1;
+    else if constexpr (H == 2) return r.v2;
+    else if constexpr (H == 3) return r.v3;
+    else return r.v4;
+}
+// the xorshift part of one step with head H (afterwards the head is (H + 1) % 5): returns the new v4; the Weyl word d is the caller's
+template <int H> SVR_DEV uint32_t rng_xorshift_rot(Rng& r)
+{
+    uint32_t& w0 = rng_word<H>(r);
+    const uint32_t w4 = rng_word<(H + 4) % 5>(r);
+    const uint32_t t = w0 ^ (w0 >> 2);
+    w0 = (w4 ^ (w4 << 4)) ^ (t ^ (t << 1));
+    return w0;
+}
+constexpr uint32_t RNG_WEYL = 362437u;
+// back to head 0 (logical v_i into field i) for a head known only at run time (the exit a lane took out of such a loop):
+// a barrel rotation, 3 x 5 selects.  The exits themselves leave every word where it is, so the loop body carries no moves.
+SVR_DEV void rng_canon(Rng& r, uint32_t head)
+{
+    uint32_t a0 = r.v0, a1 = r.v1, a2 = r.v2, a3 = r.v3, a4 = r.v4;
+    if (head & 1u) { const uint32_t t0 = a0; a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = t0; }
+    if (head & 2u) { const uint32_t t0 = a0, t1 = a1; a0 = a2; a1 = a3; a2 = a4; a3 = t0; a4 = t1; }
+    if (head & 4u) { const uint32_t t4 = a4; a4 = a3; a3 = a2; a2 = a1; a1 = a0; a0 = t4; }
+    r.v0 = a0; r.v1 = a1; r.v2 = a2; r.v3 = a3; r.v4 = a4;
+}
+template <int H> struct RngHead { static constexpr int value = H; };
 
 // pathtracer.cu:70-79 (host side too; see svr_api)
 __host__ __device__ inline uint32_t wang_hash(uint32_t a)

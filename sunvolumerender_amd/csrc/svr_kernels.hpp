@@ -54,6 +54,8 @@ hipError_t launch_pathtrace(const DevScene& scene, const DevWork& work, const La
 hipError_t launch_resolve(const DevScene& scene, const DevWork& work, hipStream_t stream);
 // default trace kernel (svr_trace_tile.hip): persistent waves, one 8x8 tile-task per wave, empty-space skipping
 hipError_t launch_trace_tile(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
+// OPT-IN local-majorant kernel (svr_trace_lm.hip): needs scene.empty_mask (class table) and scene.ray_skip; folding launches need work.pend
+hipError_t launch_trace_lm(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
 // wavefront kernels (svr_wavefront.hip): gen -> [walk -> shade] x depth over dense queues with ballot/prefix-sum
 // compaction; planes = WF_QUEUE_PLANES device arrays of `capacity` float4, counts = 32 words
 hipError_t launch_wavefront(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, float4* const* planes,

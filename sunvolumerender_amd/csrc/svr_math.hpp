@@ -20,6 +20,12 @@ namespace svr {
 SVR_DEV uint32_t f2u(float f) { return __float_as_uint(f); }
 SVR_DEV float u2f(uint32_t u) { return __uint_as_float(u); }
 SVR_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// the smallest float above x (x finite or +inf, not NaN): y > x  <=>  y >= next_up(x)
+SVR_DEV float next_up(float x)
+{
+    const uint32_t b = __float_as_uint(x);
+    return x > 0.f ? (b == 0x7f800000u ? x : __uint_as_float(b + 1u)) : (x < 0.f ? __uint_as_float(b - 1u) : __uint_as_float(1u));
+}
 
 #define SVR_INF_BITS 0x7f800000u
 #define SVR_NAN_BITS 0x7fc00000u

@@ -417,15 +417,45 @@ SVR_DEV float walk_run(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rn
         //      distance draw + log, the exit test, and the state update of the accept draw (its value is unused) ----
         bool pending = false;           // t has been advanced and still needs its tap and accept draw
         if (SKIP) {
+            // Two generator steps per iteration (distance draw, accept draw): the loop runs 5 iterations per trip with the
+            // generator as a circular buffer (rng_xorshift_rot, heads 0 2 4 1 3), so no state word is ever moved -- the
+            // shifting form spent 14-19 of its ~65 vector instructions per iteration on v_mov -- and with the Weyl word
+            // advanced once per trip.  One exit test: t >= t_stop covers `t > tMax` (woodcock_tracking.h:36) and `the first
+            // possibly-occupied cell is reached`.  A lane leaves from iteration `jx` of a trip after 2 jx + 1 steps.
+            const float t_stop = t_occ <= tMax ? t_occ : next_up(tMax);
+            uint32_t jx = 0u, d0 = rng.d;
+            auto prefix_iter = [&](auto hd, auto jj) -> bool {
+                constexpr int H = decltype(hd)::value;
+                constexpr uint32_t J = (uint32_t)decltype(jj)::value;
+                if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; else c.ipre++; }
+                const uint32_t x = rng_xorshift_rot<H>(rng) + (d0 + (2u * J + 1u) * RNG_WEYL);
+                t += -logf_unit(1.f - rng_to_uniform(x)) * s.invSigmaMaxSI;
+                jx = J;
+                if (t >= t_stop) return true;
+                if (COUNT) c.taps++;
+                rng_xorshift_rot<(H + 1) % 5>(rng);
+                return false;
+            };
             #pragma nounroll
             for (;;) {
-                if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; else c.ipre++; }
-                t += -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-                if (t > tMax || guard++ >= SVR_WALK_GUARD) return -SVR_FLT_MAX;
-                if (COUNT) c.taps++;
-                if (t >= t_occ) { pending = true; if (COUNT) { c.ipre -= !(ray_skippable || tail_counted); } break; }
-                rng_skip(rng);
+                if ((guard += 5u) > SVR_WALK_GUARD) { rng.d = d0; return -SVR_FLT_MAX; }       // (the hang guard counts trips here: checked every 5th iteration)
+                if (prefix_iter(RngHead<0>{}, RngHead<0>{})) break;
+                if (prefix_iter(RngHead<2>{}, RngHead<1>{})) break;
+                if (prefix_iter(RngHead<4>{}, RngHead<2>{})) break;
+                if (prefix_iter(RngHead<1>{}, RngHead<3>{})) break;
+                if (prefix_iter(RngHead<3>{}, RngHead<4>{})) break;
+                d0 += 10u * RNG_WEYL;
             }
+            {
+                // back to the shifting form (dead code when no draw of the path follows a walk that ends here)
+                const uint32_t steps = 2u * jx + 1u;
+                rng.d = d0 + steps * RNG_WEYL;
+                rng_canon(rng, steps >= 5u ? steps - 5u : steps);
+            }
+            if (t > tMax) return -SVR_FLT_MAX;
+            if (COUNT) c.taps++;
+            pending = true;
+            if (COUNT) { c.ipre -= !(ray_skippable || tail_counted); }
         }
         // ---- general iterations (loop rotated: tap first, then advance) ----
         uint32_t clear_run = 0;

@@ -118,6 +118,21 @@ def test_c3_bench_shape_full_frame_vs_oracle(c3):
     assert_bit_exact(hdr64[y0:y1, x0:x1], ref64[y0:y1, x0:x1], "c3 frames 32..63 continue the running mean")
 
 
+def test_c3_bench_step_256spp_vs_oracle(c3):
+    """bench.py's step EXACTLY: c3, the whole frame, ONE svr_render_pathtracer_frames call of 256 frames = 4 folding launches
+    of 64 frames (a wave = one pixel x 64 frames, queue machine on by the AUTO rule), production build.  Four 128x32
+    windows (centre of the head, its silhouette, a corner with nothing but the environment, the lower edge) of the HDR
+    accumulator and of the RGBA8 image against 256 oracle frames (4.2 M paths)."""
+    sc = c3.sc
+    hdr, img, _ = c3.run(256, batch=True, count=False)
+    wins = [(448, 496, 576, 528), (256, 300, 384, 332), (0, 0, 128, 32), (512, 992, 640, 1024)]
+    ref_hdr, ref_img, _ = _oracle_windows(sc, wins, 256)
+    for (x0, y0, x1, y1) in wins:
+        assert_bit_exact(hdr[y0:y1, x0:x1], ref_hdr[y0:y1, x0:x1], f"c3, one 256-frame call, window {(x0, y0, x1, y1)}")
+        assert np.array_equal(img[y0:y1, x0:x1], ref_img[y0:y1, x0:x1]), f"LDR window {(x0, y0, x1, y1)}"
+    assert np.isfinite(hdr).all() and hdr[512, 512].max() > 0
+
+
 def test_c3_bench_shape_properties(c3):
     """At the same shape (full frame, one 32-frame launch): skipping on == empty-space skipping off == whole-ray
     skipping off == the reference-shaped one-thread-per-pixel kernel == the counting build == 32 per-frame calls

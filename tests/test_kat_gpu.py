@@ -4,6 +4,8 @@ evaluated on the committed golden vectors -- no oracle in the loop, tolerance 0.
 * schlick_fresnel against tests/golden/fresnel_ref.npz, whose outputs came from the reference's OWN
   core/bsdf/fresnel.h compiled where it lies (oracle/ref_fresnel.cpp): the one function of the path that is pinned
   to the reference's code, now pinned on the GPU too.
+* wangHash against tests/golden/wanghash_ref.npz, likewise from the reference's own text (pathtracer.cu:70-79,
+  oracle/ref_wanghash.cpp).
 * libm (logf/expf/sinf/cosf/acosf/atan2f/powf), XORWOW uniforms and wangHash against tests/golden/kat.npz.
 """
 import ctypes as C
@@ -60,3 +62,10 @@ def test_device_rng_and_hash_match_golden(hip_dev):
     _same_bits(_eval(hip_dev, FN_UNIFORM, s, j), uni.ravel(), "curand_uniform sequence")
     got = _eval(hip_dev, FN_WANG, k["wang_in"].view(np.float32)).view(np.uint32)
     assert np.array_equal(got, k["wang_out"])
+
+
+def test_device_wang_hash_matches_the_references_own_code(hip_dev):
+    """tests/golden/wanghash_ref.npz came from the reference's own wangHash (pathtracer.cu:70-79, oracle/ref_wanghash.cpp)."""
+    z = np.load(GOLD / "wanghash_ref.npz")
+    got = _eval(hip_dev, FN_WANG, z["a"].view(np.float32)).view(np.uint32)
+    assert np.array_equal(got, z["out"])

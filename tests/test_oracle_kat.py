@@ -301,6 +301,26 @@ def test_schlick_fresnel_against_the_reference_itself(oracle):
             assert np.float32(ref.ref_schlick_fresnel(a, b, c)).view(np.uint32) == np.float32(oracle.svo_schlick(a, b, c)).view(np.uint32)
 
 
+def test_wang_hash_against_the_reference_itself(oracle):
+    """wangHash (pathtracer.cu:70-79), the seed hash of every frame, from the reference's OWN text: the line range is cut
+    out of /root/reference/pathtracer.cu at build time and compiled against the genuine cuda_runtime.h
+    (oracle/ref_wanghash.cpp).  The oracle, the library's host-side hash (sunvolumerender_amd.scenes.wang_hash_np uses the
+    same arithmetic for the synthetic volumes) and, where /root/reference exists, the live reference library agree with the
+    committed outputs."""
+    from pathlib import Path
+    from oracle import binding
+    from sunvolumerender_amd.scenes import wang_hash_np
+    g = np.load(Path(__file__).parent / "golden" / "wanghash_ref.npz")
+    mine = np.array([oracle.svo_wang_hash(int(a)) for a in g["a"]], dtype=np.uint32)
+    assert np.array_equal(mine, g["out"])
+    assert np.array_equal(wang_hash_np(g["a"]), g["out"])
+    ref = binding.wanghash_ref()
+    if ref is not None:
+        rs = np.random.RandomState(4)
+        for a in rs.randint(0, 2 ** 32, 2000, dtype=np.uint64):
+            assert ref.ref_wang_hash(int(a)) == oracle.svo_wang_hash(int(a))
+
+
 def test_config_c1_cpu_plumbing():
     """BASELINE config 0 -- the reference's own CPU-runnable case: ray casting (and one path-traced frame) of the 64^3
     sphere at 256^2 through the oracle alone, no GPU.  Deterministic, image properties as expected, and the images'
