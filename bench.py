@@ -10,8 +10,10 @@ bit-identical to 256 render_pathtracer calls (`--spp-per-step 1` is the referenc
 `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (torch.distributed.run,
 before this process touches the GPU); under an external launcher (RANK / WORLD_SIZE set) it is one of the ranks.  With
 N > 1 the frame is sharded into interleaved 16-row strips (global per-pixel seeds: the assembled image is bit-identical
-to one GPU's); inside the timed region the ranks' strips are gathered onto rank 0 over RCCL (one collective per output,
-sunvolumerender_amd.dist.FrameAssembler) and rank 0 tone-maps the assembled frame (svr_hdr_to_ldr_frame).
+to one GPU's); EVERY step ends like a one-GPU step, in a tone-mapped image of the whole frame: the ranks' strips are
+gathered onto rank 0 over RCCL (one collective per output = per step, sunvolumerender_amd.dist.FrameAssembler) and rank 0
+tone-maps the assembled frame (svr_hdr_to_ldr_frame), all inside the timed region; the ranks skip the tone map of their own
+strips (SVR_OPT_SKIP_TONEMAP), whose result nobody would read.
 
 One JSON line on rank 0 (the task contract's fields) plus
   roofline      what bounds the dominant kernel (k_trace_tile).  The counters say vector-instruction issue, not HBM
@@ -25,7 +27,11 @@ One JSON line on rank 0 (the task contract's fields) plus
   workloads     the same measurement on the scenes where nothing can be skipped and algorithmic bytes = executed
                 bytes: c3 with noisy, non-zero air (`c3n`), and c3 with empty-space skipping switched off; the headline
                 scene in the opt-in fast-math mode, and at trace depth 2 and 4.
-  cpu_baseline  the CPU oracle (a plain-C port of the reference's arithmetic, OpenMP) on a bounded sample.
+  summary       Msamples/s of every secondary workload, early in the line (details under `workloads`): noisy air, skipping
+                off, depth 2 / 4, the opt-in fast-math mode, and the OPT-IN local-majorant mode (SVR_OPT_LOCAL_MAJORANT,
+                "Woodcock max-density acceleration": not bit-identical, converged images agree) on c3, c3n and c5.
+  cpu_baseline  the CPU oracle (a plain-C port of the reference's arithmetic, OpenMP) on a bounded sample: on the box's CPU
+                share of one GPU (16 threads) and on all host cores (`value_all`, `cores_all`).
 """
 from __future__ import annotations
 
@@ -117,10 +123,28 @@ def cpu_baseline(scene, trace_depth, budget_s):
         if time.perf_counter() - t1 > budget_s * 0.4:
             break
     rc_dt = time.perf_counter() - t1
+    # the same bands on every host core (north star: "timed on the host cores (core count stated)"), a few seconds
+    all_threads = int(o.lib.svo_max_threads())
+    value_all = None
+    if all_threads > threads and budget_s >= 5:
+        hdr2 = o.new_hdr()
+        for w in bands:
+            o.render_pathtracer(hdr2, 0, trace_depth=trace_depth, window=w, count=False, nthreads=all_threads)      # (thread start-up)
+        t2 = time.perf_counter()
+        fr2 = 0
+        while fr2 < 256:
+            for w in bands:
+                o.render_pathtracer(hdr2, fr2, trace_depth=trace_depth, window=w, count=False, nthreads=all_threads)
+            fr2 += 1
+            if time.perf_counter() - t2 > min(5.0, budget_s * 0.3):
+                break
+        value_all = round(band_px * fr2 / (time.perf_counter() - t2) / 1e6, 4)
     return {
         "value": round(pt_rate, 4),
         "unit": "Msamples/s",
         "cores": threads,
+        "value_all": value_all,
+        "cores_all": all_threads if value_all is not None else None,
         "kind": "port",
         "sample": f"oracle path tracer, {frames} progressive frame(s) of {len(bands)} bands of 32 rows "
                   f"(every 128 rows) of the {W}x{H} frame = {band_px * frames} paths in {dt:.1f} s",
@@ -148,10 +172,15 @@ def kernel_source_hash() -> str:
     return h()
 
 
-def pmc_record(tag: str):
-    """profiles/r02_pmc_<tag>.json: per-launch averages of the rocprofv3 --pmc passes of this workload (tools/pmc_json.py)."""
-    f = ROOT / "profiles" / f"r02_pmc_{tag}.json"
-    if not f.exists():
+PMC_ROUND = "r03"
+
+
+def pmc_record(tag: str, default_shape: bool = True):
+    """profiles/r03_pmc_<tag>.json: per-launch averages of the rocprofv3 --pmc passes of this workload (tools/pmc_json.py).
+    The records were taken at the default launch shape (64 frames per launch, automatic layout / queue / block count, no
+    experiment option): a run with another shape gets no record, so its roofline fraction is null rather than wrong."""
+    f = ROOT / "profiles" / f"{PMC_ROUND}_pmc_{tag}.json"
+    if not default_shape or not f.exists():
         return None
     try:
         rec = json.loads(f.read_text())
@@ -236,6 +265,36 @@ def roofline_block(counters, S, steps, k_ms, k_n, pmc):
     return roof
 
 
+ROOF_HEAD = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_avg_ms", "lane_utilisation", "hbm_frac_traffic",
+             "executed_demand_frac", "pmc_source", "pmc_stale")
+
+
+def compact_first(out: dict) -> dict:
+    """The same record with what a reader needs FIRST: the contract's fields, the roofline's headline keys, the CPU baseline and
+    one number per secondary workload (`summary`, Msamples/s, with the roofline fraction where a PMC record exists) -- the
+    first ~2000 characters of the line are self-sufficient; the long blocks follow."""
+    roof = out.get("roofline") or {}
+    head = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                "dtype", "data") if k in out}
+    cfg = dict(out.get("config") or {})
+    head["config"] = {k: cfg[k] for k in ("workload", "math", "parallelism") if k in cfg}
+    head["roofline"] = {k: roof[k] for k in ROOF_HEAD if k in roof}
+    cb = out.get("cpu_baseline")
+    head["cpu_baseline"] = None if cb is None else {k: cb[k] for k in ("value", "unit", "cores", "value_all", "cores_all", "kind", "sample") if k in cb}
+    if out.get("workloads"):
+        head["summary"] = {t: ([w["value"], w["roofline"].get("frac")] if w["roofline"].get("frac") is not None else w["value"])
+                           for t, w in out["workloads"].items()}
+        head["summary_unit"] = "Msamples/s (and roofline.frac of that workload's kernel where a PMC record exists)"
+    head["config_detail"] = {k: v for k, v in cfg.items() if k not in head["config"]}
+    head["roofline_detail"] = {k: v for k, v in roof.items() if k not in head["roofline"]}
+    if cb is not None:
+        head["cpu_baseline_detail"] = {k: v for k, v in cb.items() if k not in head["cpu_baseline"]}
+    for k in ("counters", "workloads"):
+        if k in out:
+            head[k] = out[k]
+    return head
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
@@ -284,8 +343,11 @@ def main():
     for kv in args.set:
         name, value = kv.split("=")
         dev.set_option(getattr(abi, "OPT_" + name.upper()), int(value))
+    # the committed PMC records describe the default launch shape only (see pmc_record)
+    default_shape = not args.set and args.layout == 0 and args.blocks_per_cu == 0 and args.spp_per_step % 64 == 0
     asm = None
     if world > 1:
+        dev.set_option(abi.OPT_SKIP_TONEMAP, 1)      # a rank's own strips are never shown: the assembled frame is tone-mapped on rank 0
         dist.shard(dev, args.strip_rows, rank, world)
         asm = dist.FrameAssembler(H, W, args.strip_rows, rank, world, dst=0, mode=args.assemble)
         frame_img = torch.zeros(H * W, dtype=torch.int32, device="cuda") if rank == 0 else None
@@ -312,11 +374,16 @@ def main():
     counters = None if args.no_count else wl.count(args.steps, S)
 
     # ---- warm-up (includes one assembly, so that its staging buffers and the RCCL channels exist) ----
-    canvas.ReStartRender()
-    for _ in range(args.warmup):
+    def full_step():
+        """One step = S more samples for every pixel AND the output a one-GPU step ends in: a tone-mapped image of the whole
+        frame (on one GPU the library's own tone map behind the last launch; on N GPUs gather + tone map on rank 0)."""
         wl.step(S)
-    if world > 1:
-        assemble_and_tonemap(wl.hdr)
+        if world > 1:
+            assemble_and_tonemap(wl.hdr)
+
+    canvas.ReStartRender()
+    for _ in range(max(args.warmup, 1 if world > 1 else 0)):     # (N > 1: at least one, so that the staging buffers and the RCCL channels exist)
+        full_step()
     # ---- timed region: exactly K steps (frames 0 .. K*S-1 of a fresh progressive render) ----
     canvas.ReStartRender()
     dev.set_option(abi.OPT_TIMING, 1)
@@ -324,9 +391,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wl.step(S)
-    if world > 1:
-        assemble_and_tonemap(wl.hdr)
+        full_step()
     barrier()
     elapsed = time.perf_counter() - t0
     dev.set_option(abi.OPT_TIMING, 0)
@@ -350,7 +415,7 @@ def main():
         samples = float(W) * H * S * args.steps
         value = samples / elapsed / 1e6
         variant = f"d{args.trace_depth}" + ("" if args.empty_skip else "_noskip") + ("_fast" if args.fast_math else "")
-        pmc = pmc_record(f"{args.scene}_{variant}") if (args.kernel in (0, 2) and world == 1) else None
+        pmc = pmc_record(f"{args.scene}_{variant}", default_shape) if (args.kernel in (0, 2) and world == 1) else None
         roof = roofline_block(counters, S, args.steps, k_ms, k_n, pmc)
         out = {
             "metric": METRIC,
@@ -372,8 +437,8 @@ def main():
                        "kernel": {0: "tile", 1: "pixel", 2: "tile", 3: "uloop"}[args.kernel],
                        "layout": {0: "auto(pair)", 1: "linear", 2: "brick", 3: "pair"}[args.layout],
                        "math": "fast (v_log/v_exp/v_rcp, opt-in)" if args.fast_math else "bit-exact contract",
-                       "parallelism": f"row-strip tiles x{world}, {args.strip_rows}-row strips, {args.assemble} onto rank 0 + "
-                                      f"full-frame tone map inside the timed region" if world > 1 else "single GPU",
+                       "parallelism": f"row-strip tiles x{world}, {args.strip_rows}-row strips; every step ends in {args.assemble} onto rank 0 + "
+                                      f"full-frame tone map (inside the timed region)" if world > 1 else "single GPU",
                        "device": dev.info(), "setup_s": round(t_setup, 1)},
             "roofline": roof,
         }
@@ -382,23 +447,38 @@ def main():
         if cnt is not None:
             out["counters"] = cnt
 
-    # ---- secondary workloads (one GPU only): nothing skippable, so algorithmic bytes = executed bytes ----
+    # ---- secondary workloads (one GPU only) ----
     if world == 1 and not args.no_extra and args.scene == "c3" and args.kernel in (0, 2):
         extra = {}
         # (the C ABI holds ONE scene per process, like the reference's __constant__ globals: the headline canvas goes
-        # first, the second canvas replaces the scene and nothing is rendered on the first one afterwards)
-        # (tag, scene, empty-skip, fast math, trace depth, what it is)
-        plan = [("c3_skip_off", "c3", 0, 0, args.trace_depth, "the headline scene with SVR_OPT_EMPTY_SKIP = 0: every tap of the reference algorithm is fetched"),
-                ("c3_fast_math", "c3", 1, 1, args.trace_depth, "the headline scene in the OPT-IN fast-math mode (SVR_OPT_FAST_MATH: v_log / reciprocal division / "
-                                                              "contraction; not bit-identical, converged images agree within Monte-Carlo noise)")]
-        if args.trace_depth == 1 and not args.fast_math:
-            plan += [(f"c3_depth{d}", "c3", 1, 0, d, f"the headline scene at trace depth {d} (the reference's GUI range is 1-10)") for d in (2, 4)]
-        plan += [("c3_noisy_air", "c3n", 1, 0, args.trace_depth, "c3 with noisy non-zero air (64..191 raw LSB, like CT data rescaled to the full u16 range): no "
-                                                                 "macro-cell is exactly transparent")]
-        for tag, sc_name, skip, fast, depth, what in plan:
-            w2 = wl if sc_name == args.scene else Workload(dev, torch, sc_name, args.trace_depth, args.layout)
+        # first, every further canvas replaces the scene and nothing is rendered on an earlier one afterwards)
+        LM_WHAT = ("in the OPT-IN local-majorant mode (SVR_OPT_LOCAL_MAJORANT, 'Woodcock max-density acceleration': delta tracking against "
+                   "per-macro-cell majorants; not bit-identical, converged images agree within Monte-Carlo noise)")
+        d0 = args.trace_depth
+        plan = [dict(tag="c3_skip_off", scene="c3", skip=0, what="the headline scene with SVR_OPT_EMPTY_SKIP = 0: every tap of the reference algorithm is fetched"),
+                dict(tag="c3_fast_math", scene="c3", fast=1, what="the headline scene in the OPT-IN fast-math mode (SVR_OPT_FAST_MATH: v_log / reciprocal division / "
+                                                                  "contraction; not bit-identical, converged images agree within Monte-Carlo noise)"),
+                dict(tag="c3_local_majorant", scene="c3", lm=1, what="the headline scene " + LM_WHAT)]
+        if d0 == 1 and not args.fast_math:
+            for d in (2, 4):
+                plan += [dict(tag=f"c3_depth{d}", scene="c3", depth=d, what=f"the headline scene at trace depth {d} (the reference's GUI range is 1-10)"),
+                         dict(tag=f"c3_depth{d}_local_majorant", scene="c3", depth=d, lm=1, what=f"the headline scene at trace depth {d} " + LM_WHAT)]
+        plan += [dict(tag="c3_noisy_air", scene="c3n", what="c3 with noisy non-zero air (64..191 raw LSB, like CT data rescaled to the full u16 range): no "
+                                                            "macro-cell is exactly transparent"),
+                 dict(tag="c3n_local_majorant", scene="c3n", lm=1, what="c3 with noisy non-zero air " + LM_WHAT),
+                 dict(tag="c5", scene="c5", what="BASELINE config 5 on one GPU: 1024^3 u16 volume (HBM-resident), 1024^2, default mode"),
+                 dict(tag="c5_local_majorant", scene="c5", lm=1, what="BASELINE config 5 on one GPU (1024^3 u16, 1024^2) " + LM_WHAT)]
+        w2, w2_scene = wl, args.scene
+        for item in plan:
+            tag, sc_name, what = item["tag"], item["scene"], item["what"]
+            skip, fast, lm, depth = item.get("skip", 1), item.get("fast", 0), item.get("lm", 0), item.get("depth", d0)
+            if sc_name != w2_scene:
+                if w2 is not wl:
+                    w2.close()
+                w2, w2_scene = Workload(dev, torch, sc_name, d0, args.layout), sc_name
             dev.set_option(abi.OPT_EMPTY_SKIP, skip)
             dev.set_option(abi.OPT_FAST_MATH, fast)
+            dev.set_option(abi.OPT_LOCAL_MAJORANT, lm)
             w2.canvas.SetScatterTimes(depth)
             n = max(1, args.extra_steps)
             c2 = None if (args.no_count or fast) else w2.count(n, S)
@@ -415,14 +495,18 @@ def main():
             dt = time.perf_counter() - t1
             dev.set_option(abi.OPT_TIMING, 0)
             ms2, n2 = dev.kernel_time()
-            r2 = roofline_block(c2, S, n, ms2, n2, None if fast else pmc_record(f"{sc_name}_d{depth}" + ("" if skip else "_noskip")))
+            rec = None if fast else pmc_record(f"{sc_name}_d{depth}" + ("" if skip else "_noskip") + ("_lm" if lm else ""), default_shape)
+            r2 = roofline_block(c2, S, n, ms2, n2, rec)
+            if lm:
+                r2["kernel"] = "k_trace_lm"
             extra[tag] = {"value": round(float(W) * H * S * n / dt / 1e6, 3), "unit": "Msamples/s", "steps": n,
                           "ms_per_step": round(dt / n * 1e3, 3), "trace_depth": depth, "what": what, "roofline": r2}
             dev.set_option(abi.OPT_EMPTY_SKIP, args.empty_skip)
             dev.set_option(abi.OPT_FAST_MATH, args.fast_math)
-            w2.canvas.SetScatterTimes(args.trace_depth)
-            if w2 is not wl:
-                w2.close()
+            dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
+            w2.canvas.SetScatterTimes(d0)
+        if w2 is not wl:
+            w2.close()
         out["workloads"] = extra
 
     if rank == 0:
@@ -430,7 +514,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene, args.trace_depth, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        print(json.dumps(compact_first(out)), flush=True)
 
     wl.close()
     if world > 1:

@@ -44,11 +44,11 @@ HIPCC_FLAGS += os.environ.get("SVR_EXTRA_HIPCC_FLAGS", "").split()
 LINK_LIBS = ["-lz"]          # MetaImage CompressedData (svr_host_io.hip)
 
 
-HOST_ONLY_SOURCES = ("svr_api.hip", "svr_host_io.hip", "svr_internal.hpp")
+HOST_ONLY_SOURCES = ("svr_host_io.hip", "svr_internal.hpp")     # (svr_api.hip holds the launch policy: queue / layout / group heuristics)
 
 
 def kernel_source_hash() -> str:
-    """Hash of the kernel sources (device code: everything but the host-side API and file I/O translation units) with comments
+    """Hash of the kernel sources (device code and the launch policy of svr_api.hip: everything but the file I/O translation unit) with comments
     and whitespace removed: the PMC records under profiles/ carry it, and bench.py flags a record made from other code as stale."""
     import hashlib
     import re
@@ -89,6 +89,13 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
     common = [CSRC / f for f in HIP_HEADERS] + [REPO_ROOT / "include" / "svr_abi.h", REPO_ROOT / "include" / "svr_io.h",
                                                 CSRC / "svr_internal.hpp", Path(__file__)]
     hipcc = _hipcc()
+    # the effective flags are part of an object's identity: a build with other flags (SVR_EXTRA_HIPCC_FLAGS=-DSVR_TEST_HOOKS ...)
+    # must not leave its objects behind for the next plain build
+    stamp = obj_dir / "flags.stamp"
+    flags_now = " ".join(HIPCC_FLAGS + ["|"] + FAST_FLAGS)
+    if not stamp.exists() or stamp.read_text() != flags_now:
+        force = True
+        stamp.write_text(flags_now)
 
     def compile_one(name: str):
         src, obj = CSRC / name, obj_dir / (Path(name).stem + ".o")

@@ -847,7 +847,19 @@ void svr_clear_error(void) { g.err_code = 0; g.err_msg.clear(); }
 const char* svr_device_info(void) { ensure_init(); return g.info.c_str(); }
 
 // ---------------- textures ----------------
+static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz, int src_is_device, int layout, bool* oom);
+
 uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz, int src_is_device, int layout)
+{
+    // AUTO prefers PAIR (twice the memory of BRICK: 552 MB for 512^3); if the device has no room for it, BRICK is tried before giving up
+    bool oom = false;
+    uint64_t h = create_volume_texture(voxels, nx, ny, nz, src_is_device, layout, layout == SVR_LAYOUT_AUTO ? &oom : nullptr);
+    if (h == 0 && oom) h = create_volume_texture(voxels, nx, ny, nz, src_is_device, SVR_LAYOUT_BRICK, nullptr);
+    return h;
+}
+
+// oom != null: running out of device memory is reported through *oom instead of as an error (the caller retries with a smaller layout)
+static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz, int src_is_device, int layout, bool* oom)
 {
     if (ensure_init()) return 0;
     if (!voxels || nx <= 0 || ny <= 0 || nz <= 0) { fail(-6, "svr_create_volume_texture: bad arguments (%p, %d, %d, %d)", (const void*)voxels, nx, ny, nz); return 0; }
@@ -909,7 +921,16 @@ uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int n
     }
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
     if (staged) hipFree(staged);
-    if (e != hipSuccess) { if (t->data) hipFree(t->data); if (t->mm) hipFree(t->mm); if (t->mm_fine) hipFree(t->mm_fine); delete t; fail((int)e, "volume texture creation failed: %s", hipGetErrorName(e)); return 0; }
+    if (e != hipSuccess) {
+        const bool retry = oom != nullptr && e == hipErrorOutOfMemory && layout == SVR_LAYOUT_PAIR;
+        if (t->data) hipFree(t->data);
+        if (t->mm) hipFree(t->mm);
+        if (t->mm_fine) hipFree(t->mm_fine);
+        delete t;
+        if (retry) { (void)hipGetLastError(); *oom = true; return 0; }
+        fail((int)e, "volume texture creation failed: %s", hipGetErrorName(e));
+        return 0;
+    }
     uint64_t h = (uint64_t)(uintptr_t)t;
     g.textures[h] = t;
     return h;

@@ -270,8 +270,11 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
             PROF_BEGIN(pfo, PH_FOLD);
             fold_pending(s, w, gpend, 64u, &pend.task[wave][0], npend);
             PROF_END(pfo, min(64u, npend * (3u << ts.P2)));
-        } else
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // pend.L / pend.task are written by one lane and read by another lane of this wave
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             fold_pending(s, w, &pend.L[wave][0][0], PEND_ROW, &pend.task[wave][0], npend);
+        }
         npend = 0;
     };
 

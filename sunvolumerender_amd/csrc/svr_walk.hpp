@@ -344,6 +344,9 @@ SVR_DEV float first_occupied_group(const DevScene& s, const LDS& L, uint32_t P2,
     }
     map.lo = lo; map.dt = dt; map.inv_dt = bmax * (1.f / 0.7f);
     map.valid = complete && ok;
+    // the group's slot was written by every lane of the group (identical values) and is read by all of them in group_map_next
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return result;
 }
 

@@ -1,0 +1,184 @@
+"""SVR_OPT_LOCAL_MAJORANT (opt-in, default off): delta tracking against per-macro-cell majorants instead of the reference's
+single global one (core/woodcock_tracking.h:29-31) -- BASELINE.json's "Woodcock max-density acceleration"
+(sunvolumerender_amd/csrc/svr_trace_lm.hip).  The law of every collision point is the reference's, the consumption of
+random numbers is not, so the mode is NOT bit-identical to the default one.  Its contract is the converged-image
+tolerance BASELINE.json's north star states, written like tests/test_fast_math_gpu.py:
+
+  A = default mode, frames 0..N-1;  B = default mode, frames N..2N-1 (an independent estimate: B = 2 mean(0..2N-1) - A);
+  F = local-majorant mode, frames 0..N-1
+  * rmse(F, B) <= 1.10 * rmse(A, B)   -- F is as close to an independent exact estimate as an exact render is
+  * rmse(F, A) <= 1.10 * rmse(A, B)   -- (F and A share only the camera draws: they are nearly independent too)
+  * |mean(F) - mean(A)| <= max(0.3 % of mean(A), 4 standard errors) per channel -- no bias
+The per-pixel L2 is taken on the IMAGE, i.e. after the reference's exposure curve c = 1 - exp(-16 L exposure)
+(core/tonemapping.h:13-21, before its pow): bounded, so the rare 1/pdf fireflies of deep paths -- which dominate an
+L2 on raw radiance and make the ratio of two such L2s a coin toss -- count as the saturated pixels they are; where the
+radiance itself is light-tailed (trace depth <= 2) the same inequalities are ALSO required on the raw HDR values.
+The means are compared on the raw HDR values always; their standard error is rmse_channel(A, B) / sqrt(pixels).
+On c2 (256^3, depth 2), c3n (noisy non-zero air: nothing is exactly transparent; depth 1 and 4) and c5 (1024^3), full
+frames; and against the ORACLE's own 256-spp image on a window (the unbiasedness check does not rest on the HIP default
+mode alone).
+Inside the mode a frame's radiance is still a pure function of (scene, pixel, frame): per-frame calls, batches, row
+shards and the counting build agree bit for bit.  The default mode is untouched by the switch."""
+import numpy as np
+import pytest
+
+from oracle import binding
+from sunvolumerender_amd import abi, host, scenes
+from tests.util import assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def _canvas(dev, name, **kw):
+    sc = scenes.make_scene(name, **kw)
+    canvas = host.Canvas(dev, sc.width, sc.height)
+    scenes.apply_to_canvas(sc, canvas)
+    return sc, canvas
+
+
+def _render(dev, canvas, lm, frames):
+    """progressive render; returns the accumulator after each entry of `frames` (cumulative calls)"""
+    dev.set_option(abi.OPT_LOCAL_MAJORANT, 1 if lm else 0)
+    canvas.ReStartRender()
+    out = []
+    for n in frames:
+        canvas.paint_frames(n)
+        dev.synchronize()
+        out.append(canvas.read_hdr().astype(np.float64))
+    dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
+    return out
+
+
+def _rmse(x, y):
+    return float(np.sqrt(np.mean((x - y) ** 2)))
+
+
+def _curve(x, exposure=1.0):
+    """the reference's exposure curve, core/tonemapping.h:13-21 (what hdr_to_ldr shows, before its pow)"""
+    return 1.0 - np.exp(-16.0 * np.maximum(x, 0.0) * exposure)
+
+
+def _check_converged(A, B, F, what, hdr_l2=True):
+    assert not np.array_equal(F, A), f"{what}: the local-majorant mode produced the default mode's bits: did it run?"
+    assert np.isfinite(F).all() and (F >= 0).all()
+    spaces = [("image", _curve(A), _curve(B), _curve(F))] + ([("hdr", A, B, F)] if hdr_l2 else [])
+    for space, a, b, f in spaces:
+        noise = _rmse(a, b)
+        assert noise > 0
+        assert _rmse(f, b) <= 1.10 * noise, (what, space, _rmse(f, b), noise)
+        assert _rmse(f, a) <= 1.10 * noise, (what, space, _rmse(f, a), noise)
+    npx = A.shape[0] * A.shape[1]
+    mA, mF = A.mean(axis=(0, 1)), F.mean(axis=(0, 1))
+    se = np.sqrt(np.mean((A - B) ** 2, axis=(0, 1)) / npx)          # standard error of mean(F) - mean(A): var(A - B) = var(F - A) per pixel
+    assert np.all(np.abs(mF - mA) <= np.maximum(3e-3 * mA, 4.0 * se)), (what, mA, mF, se)
+
+
+@pytest.mark.parametrize("name,depth,spp", [("c2", 2, 256), ("c3n", 1, 128), ("c3n", 4, 64), ("c5", 1, 128)])
+def test_local_majorant_converged_image_within_noise(hip_dev, name, depth, spp):
+    sc, canvas = _canvas(hip_dev, name, trace_depth=depth)
+    try:
+        A, A2 = _render(hip_dev, canvas, False, (spp, spp))
+        B = 2.0 * A2 - A
+        (F,) = _render(hip_dev, canvas, True, (spp,))
+        _check_converged(A, B, F, f"{name} depth {depth}", hdr_l2=depth <= 2)
+        # the default mode is untouched by the switch
+        (A3,) = _render(hip_dev, canvas, False, (spp,))
+        assert_bit_exact(A3.astype(np.float32), A.astype(np.float32), "default mode after the local-majorant mode was used")
+    finally:
+        hip_dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
+        canvas.close()
+
+
+def test_local_majorant_unbiased_against_the_oracle(hip_dev):
+    """The same three inequalities with the ORACLE in the place of the default mode: a 96x48 window of small_head (128^3,
+    256^2, 3 lights + env, depth 2) at 256 spp; O = oracle frames 0..255, O2 = oracle frames 256..511."""
+    sc, canvas = _canvas(hip_dev, "small_head", trace_depth=2)
+    try:
+        N = 256
+        win = (80, 100, 176, 148)
+        x0, y0, x1, y1 = win
+        o = binding.OracleScene(sc)
+        acc = o.new_hdr()
+        for f in range(N):
+            o.render_pathtracer(acc, f, trace_depth=2, window=win, count=False)
+        O = acc[y0:y1, x0:x1].astype(np.float64)
+        for f in range(N, 2 * N):
+            o.render_pathtracer(acc, f, trace_depth=2, window=win, count=False)
+        O2 = 2.0 * acc[y0:y1, x0:x1].astype(np.float64) - O
+        (F,) = _render(hip_dev, canvas, True, (N,))
+        _check_converged(O, O2, F[y0:y1, x0:x1], "small_head window vs oracle")
+    finally:
+        hip_dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
+        canvas.close()
+
+
+@pytest.mark.parametrize("name,depth", [("tiny_head", 1), ("tiny_head", 3), ("tiny_head_noisy", 2), ("small_head", 1)])
+def test_local_majorant_is_a_pure_function_of_scene_pixel_frame(hip_dev, name, depth):
+    """Inside the mode: one 24-frame call == 24 render_pathtracer calls (frames traced ahead, scratch slots + k_resolve) ==
+    the counting build == the union of 3 row shards; and rendering twice gives the same bits."""
+    sc, canvas = _canvas(hip_dev, name, trace_depth=depth)
+    dev = hip_dev
+    try:
+        N = 24
+        dev.set_option(abi.OPT_LOCAL_MAJORANT, 1)
+
+        def run(batch=True, count=False, shard=None):
+            dev.set_option(abi.OPT_COUNT, 1 if count else 0)
+            if shard is not None:
+                dev.check(dev.lib.svr_set_row_shard(*shard))
+            dev.reset_counters()
+            canvas.ReStartRender()
+            if batch:
+                canvas.paint_frames(N)
+            else:
+                for _ in range(N):
+                    canvas.paint()
+            dev.synchronize()
+            dev.lib.svr_set_row_shard(0, 0, 1)
+            dev.set_option(abi.OPT_COUNT, 0)
+            return canvas.read_hdr(), canvas.read_img(), dev.counters()
+
+        a, ai, _ = run()
+        b, bi, _ = run()
+        assert_bit_exact(a, b, "local-majorant mode, rendered twice")
+        c, ci, cnt = run(count=True)
+        assert_bit_exact(a, c, "local-majorant mode: counting build")
+        assert np.array_equal(ai, ci)
+        assert cnt["paths"] == sc.width * sc.height * N and 0 < cnt["vol_taps_executed"] and cnt["scatter_events"] > 0
+        d, di, _ = run(batch=False)
+        assert_bit_exact(a, d, "local-majorant mode: 24 render_pathtracer calls vs one 24-frame call")
+        assert np.array_equal(ai, di)
+        union = np.zeros_like(a)
+        for r in range(3):
+            part, _, _ = run(shard=(8, r, 3))
+            rows = [y for y in range(sc.height) if (y // 8) % 3 == r]
+            union[rows] = part[rows]
+        assert_bit_exact(a, union, "local-majorant mode: union of 3 row shards")
+        # and it is not the default mode's image
+        dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
+        e, _, _ = run()
+        assert not np.array_equal(a, e)
+    finally:
+        dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
+        dev.set_option(abi.OPT_COUNT, 0)
+        dev.lib.svr_set_row_shard(0, 0, 1)
+        canvas.close()
+
+
+def test_local_majorant_falls_back_where_it_cannot_run(hip_dev):
+    """Without the acceleration data (SVR_OPT_EMPTY_SKIP = 0) the switch is inert: the default kernel renders, bit-exact."""
+    sc, canvas = _canvas(hip_dev, "tiny_head", trace_depth=2)
+    dev = hip_dev
+    try:
+        canvas.ReStartRender()
+        canvas.paint_frames(8, sync=True)
+        ref = canvas.read_hdr()
+        dev.set_option(abi.OPT_LOCAL_MAJORANT, 1)
+        dev.set_option(abi.OPT_EMPTY_SKIP, 0)
+        canvas.ReStartRender()
+        canvas.paint_frames(8, sync=True)
+        assert_bit_exact(canvas.read_hdr(), ref, "LOCAL_MAJORANT with EMPTY_SKIP = 0 renders with the default kernel")
+    finally:
+        dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
+        dev.set_option(abi.OPT_EMPTY_SKIP, 1)
+        canvas.close()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn a tools/profile.sh summary into the per-launch PMC record bench.py reads (profiles/r02_pmc_<tag>.json).
+"""Turn a tools/profile.sh summary into the per-launch PMC record bench.py reads (profiles/r03_pmc_<tag>.json).
 Usage: tools/pmc_json.py <summary.txt> <kernel-prefix> <tag> <out.json> [note]
 Counters are per-dispatch averages of separate rocprofv3 --pmc passes; FETCH_SIZE is doubled per the gfx950
 correction of MI355X_MICROARCH.md (HBM section)."""
@@ -27,7 +27,9 @@ for line in open(summary):
 sys.path.insert(0, str(ROOT))
 from sunvolumerender_amd._build import kernel_source_hash  # noqa: E402
 rec = {"source": f"{summary} (rocprofv3 --kernel-trace --stats, then separate --pmc passes; per-dispatch averages)", "kernel": kernel, "tag": tag,
-       "note": note, "kernel_source_hash": kernel_source_hash()}
+       "note": note, "kernel_source_hash": kernel_source_hash(),
+       # what bench.py calls the default launch shape: the only one it uses the record for
+       "launch_shape": {"frames_per_launch": 64, "layout": "auto", "queue": "auto", "blocks_per_cu": "default", "extra_options": []}}
 if stats:
     rec["rocprof_kernel_avg_ms"] = stats["avg_ns"] / 1e6
     rec["rocprof_kernel_calls"] = stats["calls"]

@@ -6,9 +6,12 @@ R=$1
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 export PMC_ONLY="${PMC_ONLY:-1 2 3 4 5 6}"
-for spec in "c3_d1:--scene c3" "c3_d1_noskip:--scene c3 --empty-skip 0" "c3n_d1:--scene c3n"; do
+SPECS=${SPECS:-"c3_d1:--scene c3|c3_d1_noskip:--scene c3 --empty-skip 0|c3n_d1:--scene c3n|c3_d1_lm:--scene c3 --set local_majorant=1|c3n_d1_lm:--scene c3n --set local_majorant=1|c5_d1_lm:--scene c5 --set local_majorant=1"}
+IFS='|' read -ra SPEC_LIST <<< "$SPECS"
+for spec in "${SPEC_LIST[@]}"; do
   tag=${spec%%:*}; args=${spec#*:}
+  kern=k_trace_tile; case $tag in *_lm) kern=k_trace_lm;; esac
   echo "=== $tag ($args)"
   PROF_STEPS=${PROF_STEPS:-1} bash tools/profile.sh ${R}_$tag $args --spp-per-step ${PROF_SPP:-64} > gpurun_out/prof_${R}_$tag.log 2>&1 || { echo "profile $tag failed"; tail -5 gpurun_out/prof_${R}_$tag.log; exit 1; }
-  python3 tools/pmc_json.py gpurun_out/prof_${R}_$tag/summary.txt "k_trace_tile" $tag gpurun_out/prof_${R}_$tag/pmc.json "bench.py $args --spp-per-step ${PROF_SPP:-64} (64 frames per launch)" | cut -c1-400
+  python3 tools/pmc_json.py gpurun_out/prof_${R}_$tag/summary.txt "$kern" $tag gpurun_out/prof_${R}_$tag/pmc.json "bench.py $args --spp-per-step ${PROF_SPP:-64} (64 frames per launch)" | cut -c1-400
 done

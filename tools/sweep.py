@@ -12,7 +12,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from sunvolumerender_amd import abi, host, scenes  # noqa: E402
 
 KEYS = {"bound_cull": abi.OPT_BOUND_CULL, "empty_skip": abi.OPT_EMPTY_SKIP, "ray_skip": abi.OPT_RAY_SKIP,
-        "fl2": abi.OPT_FRAMES_PER_WAVE_LOG2, "kernel": abi.OPT_KERNEL, "frame_ahead": abi.OPT_FRAME_AHEAD, "fast_math": abi.OPT_FAST_MATH, "fold": abi.OPT_FOLD, "queue": abi.OPT_QUEUE, "park_end": abi.OPT_PARK_END, "fine_mask": abi.OPT_FINE_MASK, "row_order": abi.OPT_ROW_ORDER, "group": abi.OPT_GROUP_FRAMES}
+        "fl2": abi.OPT_FRAMES_PER_WAVE_LOG2, "kernel": abi.OPT_KERNEL, "frame_ahead": abi.OPT_FRAME_AHEAD, "fast_math": abi.OPT_FAST_MATH, "fold": abi.OPT_FOLD, "queue": abi.OPT_QUEUE, "park_end": abi.OPT_PARK_END, "fine_mask": abi.OPT_FINE_MASK, "row_order": abi.OPT_ROW_ORDER, "group": abi.OPT_GROUP_FRAMES, "lm": abi.OPT_LOCAL_MAJORANT}
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="c3")
 ap.add_argument("--depth", type=int, default=1)
@@ -73,6 +73,6 @@ for setting in a.settings:
         k = dev.counters()
         dev.set_option(abi.OPT_COUNT, 0)
         p = max(1, k["paths"])
-        extra = f"  taps/path {k['vol_taps'] / p:.1f} fetched {k['vol_taps_executed'] / p:.2f} culled {k['taps_bound_culled'] / p:.2f} iters {k['woodcock_iters'] / p:.1f}"
+        extra = f"  taps/path {k['vol_taps'] / p:.1f} fetched {k['vol_taps_executed'] / p:.2f} culled {k['taps_bound_culled'] / p:.2f} iters {k['woodcock_iters'] / p:.1f} prefix/dda {k.get('iters_prefix_skipped', 0) / p:.1f}"
     print(f"{setting or 'defaults':40s} {best:8.4f} ms/frame {sc.width * sc.height / best / 1e3:9.1f} Msamples/s{extra}", flush=True)
 c.close()
