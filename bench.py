@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--trace-depth", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=256)
     ap.add_argument("--kernel", type=int, default=0, help="0 auto(=2), 1 block-per-tile baseline, 2 persistent tile kernel, 3 lane state machine")
-    ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 linear, 2 brick, 3 pair")
+    ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 linear, 2 brick, 3 pair, 4 cell")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--strip-rows", type=int, default=16, help="rows per interleaved strip under row sharding (16: max/mean rank time 1.02 at 8 ranks on c3, 32: 1.08)")
     ap.add_argument("--assemble", default="gather", choices=["gather", "reduce"], help="collective that assembles the frame on rank 0")
@@ -435,7 +435,7 @@ def main():
                                    f"trace depth {args.trace_depth}, {S} spp per step",
                        "spp_per_step": S, "trace_depth": args.trace_depth,
                        "kernel": {0: "tile", 1: "pixel", 2: "tile", 3: "uloop"}[args.kernel],
-                       "layout": {0: "auto(pair)", 1: "linear", 2: "brick", 3: "pair"}[args.layout],
+                       "layout": {0: "auto", 1: "linear", 2: "brick", 3: "pair", 4: "cell"}[args.layout],
                        "math": "fast (v_log/v_exp/v_rcp, opt-in)" if args.fast_math else "bit-exact contract",
                        "parallelism": f"row-strip tiles x{world}, {args.strip_rows}-row strips; every step ends in {args.assemble} onto rank 0 + "
                                       f"full-frame tone map (inside the timed region)" if world > 1 else "single GPU",

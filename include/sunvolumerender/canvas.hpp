@@ -320,6 +320,7 @@ public:
     }
 
     uint32_t FrameNo() const { return renderParams.frameNo; }
+    void* HdrBuffer() const { return renderParams.hdrBuffer; }               // the accumulator (device): what svr_assemble_frame sends
     const cudaCamera& Camera() const { return camera; }
     const cudaVolume& Volume() const { return deviceVolume; }
 

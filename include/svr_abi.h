@@ -150,6 +150,8 @@ void svr_clear_error(void);
 #define SVR_LAYOUT_BRICK 2           /* 8x4x4-voxel bricks (256 B), 2-voxel zero apron */
 #define SVR_LAYOUT_PAIR 3            /* the same bricks with 32-bit elements: voxel x | voxel x+1 << 16 (half the gather instructions per
                                         trilinear fetch, twice the memory); volumes up to ~1000^3; what AUTO picks when it fits */
+#define SVR_LAYOUT_CELL 4            /* the same bricks with 16-byte elements: the 8 voxels of a trilinear cell -- one 16-byte load per fetch, one 32-byte
+                                     * sector instead of four; 8 x the memory of the u16 volume (2.2 GB for 512^3), volumes up to ~640^3 (32-bit offsets) */
 uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz,
                                    int src_is_device, int layout);
 /* gui/transferfunction.cpp:30-44 (1D float4 array, clamp / linear / normalized coords). */
@@ -179,6 +181,28 @@ int svr_memset_device(void* dst_device, int value, size_t bytes);
 int svr_set_row_shard(uint32_t strip_rows, uint32_t rank, uint32_t world);
 /* Restrict to the pixel window [x0,x1) x [y0,y1) (combined with the row shard). Negative x1/y1 = full. */
 int svr_set_render_window(int x0, int y0, int x1, int y1);
+
+/* ---- frame assembly for row-sharded renders: the native counterpart of sunvolumerender_amd/dist.py's FrameAssembler ----
+ * A rank's accumulator holds the rows it owns (svr_set_row_shard) and zeros elsewhere.  The rows of rank r, in increasing
+ * y, form its PACKED buffer: svr_strip_rows_owned() rows of W x float3.  One collective per output frame: every rank packs
+ * and sends its rows to `root`, root unpacks them into the full frame -- with RCCL one point-to-point transfer per peer
+ * over its own xGMI link (1.5 MB per peer at 1024^2 on 8 GPUs).
+ * The two index functions are plain host code (no GPU needed). */
+uint32_t svr_strip_rows_owned(uint32_t H, uint32_t strip_rows, uint32_t rank, uint32_t world);
+/* y of the p-th owned row (p < svr_strip_rows_owned); 0xffffffff if p is out of range */
+uint32_t svr_strip_row_to_y(uint32_t p, uint32_t H, uint32_t strip_rows, uint32_t rank, uint32_t world);
+/* device buffers, on the library's stream: packed <- the rows of `rank` out of the full-size W x H x float3 `hdr`, and back */
+int svr_pack_strips(void* packed, const void* hdr, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t rank, uint32_t world);
+int svr_unpack_strips(void* frame, const void* packed, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t rank, uint32_t world);
+/* The whole exchange, for a host that holds an RCCL communicator (one process per GPU, as with sunvolumerender_amd.dist):
+ * nccl_comm = the host's ncclComm_t (world ranks; rank / world must be its rank / size).  Every rank packs its rows of
+ * hdr_local (its accumulator; not modified) and ncclSend()s them to `root`; root ncclRecv()s the peers' rows and unpacks all of
+ * them into frame_on_root (W x H x float3, device; ignored on the other ranks).  Enqueued on the library's stream
+ * (svr_set_stream); the staging buffer is the library's.  RCCL is resolved at the first call from the library the process
+ * has already loaded (dlopen("librccl.so")), so libsvr_hip.so itself does not link against it.
+ * Afterwards svr_hdr_to_ldr_frame(img, frame_on_root, W, H) tone-maps the assembled frame on root. */
+int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_local, uint32_t W, uint32_t H,
+                       uint32_t strip_rows, uint32_t rank, uint32_t world, uint32_t root);
 
 #define SVR_OPT_ENV_ON_ESCAPE 1   /* 1: add T*env(dir) when a path leaves the volume (the line the reference
                                      comments out, pathtracer.cu:233).  default 0 = reference behaviour */
@@ -225,6 +249,9 @@ int svr_set_render_window(int x0, int y0, int x1, int y1);
                                      * collision point, far fewer iterations, but a different consumption of random numbers.  NOT bit-identical to
                                      * the default mode; converged images agree within Monte-Carlo noise (tests/test_local_majorant_gpu.py).  Needs
                                      * SVR_OPT_EMPTY_SKIP = 1 and clip planes inside the volume; otherwise the default kernel renders */
+#define SVR_OPT_LIGHT_CULL 24       /* 1 (default): area lights that no camera ray can reach (behind the lens plane or outside the view frustum, lens
+                                     * and pixel jitter included; conservative host-side test) are skipped by the primary rays' nearest-light test
+                                     * (core/lights/light_sample.h:23-49).  Results unchanged */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */

@@ -41,7 +41,7 @@ HIPCC_FLAGS = [
 ]
 # extra compile flags for experiment builds (e.g. -DSVR_TEST_HOOKS: the timing-ablation options of tools/exp.py)
 HIPCC_FLAGS += os.environ.get("SVR_EXTRA_HIPCC_FLAGS", "").split()
-LINK_LIBS = ["-lz"]          # MetaImage CompressedData (svr_host_io.hip)
+LINK_LIBS = ["-lz", "-ldl"]  # MetaImage CompressedData (svr_host_io.hip); dlopen of the process's RCCL (svr_assemble_frame)
 
 
 HOST_ONLY_SOURCES = ("svr_host_io.hip", "svr_internal.hpp")     # (svr_api.hip holds the launch policy: queue / layout / group heuristics)

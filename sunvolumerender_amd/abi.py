@@ -130,7 +130,7 @@ for _t, _n in EXPECTED_SIZES.items():
 MAX_LIGHT_SOURCES = 8
 TF_TABLE_SIZE = 1024
 
-LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_BRICK, LAYOUT_PAIR = 0, 1, 2, 3
+LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_BRICK, LAYOUT_PAIR, LAYOUT_CELL = 0, 1, 2, 3, 4
 OPT_ENV_ON_ESCAPE, OPT_KERNEL, OPT_COUNT, OPT_TIMING, OPT_SKIP_TONEMAP, OPT_BLOCKS_PER_CU = 1, 2, 3, 4, 5, 6
 OPT_PIPELINE, OPT_REFILL_MIN_IDLE, OPT_EMPTY_SKIP, OPT_RAY_SKIP, OPT_FRAMES_PER_WAVE_LOG2 = 7, 8, 9, 10, 11
 OPT_RAYCAST_LANES_LOG2 = 12
@@ -144,6 +144,7 @@ OPT_FINE_MASK = 20
 OPT_ROW_ORDER = 21
 OPT_GROUP_FRAMES = 22
 OPT_LOCAL_MAJORANT = 23
+OPT_LIGHT_CULL = 24
 KERNEL_AUTO, KERNEL_PIXEL, KERNEL_TILE, KERNEL_ULOOP, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4
 
 ELEM_I8, ELEM_U8, ELEM_I16, ELEM_U16, ELEM_I32, ELEM_U32, ELEM_F32, ELEM_F64 = range(8)
@@ -197,6 +198,11 @@ PROTOTYPES = {
     "svr_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "svr_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "svr_memset_device": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
+    "svr_strip_rows_owned": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svr_strip_row_to_y": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svr_pack_strips": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svr_unpack_strips": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svr_assemble_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "svr_set_row_shard": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "svr_set_render_window": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "svr_set_option": (C.c_int, [C.c_int, C.c_int]),

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -120,7 +121,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -148,6 +149,8 @@ struct Context {
 
 Context g;
 std::mutex g_mu;
+float* g_stage = nullptr;          // svr_assemble_frame: packed rows -- this rank's, and on root every rank's
+size_t g_stage_floats = 0;
 
 int fail(int code, const char* fmt, ...)
 {
@@ -300,6 +303,34 @@ int build_scene(const svr_volume& vol, const svr_transfer_function& tf, const sv
     return 0;
 }
 
+// Can a camera ray (cudaCamera::GenerateRay, core/cuda_camera.h:66-83) reach the disk?  Conservative: true unless the disk's
+// bounding sphere lies behind the lens plane or outside the view frustum widened by the lens.  A ray leaves the lens point a
+// (|a| <= aperture) towards the image-plane point n at depth f = focalLength; at depth z > 0 its lateral offset is
+// a (1 - z / f) + n z / f, with |n_x| <= (1 + 2 / (W - 1)) aspect tan(fov / 2) f (pixel jitter included).
+bool light_reachable_by_camera_rays(const svr::DevScene& s, const svr_area_light& l)
+{
+    const double f = s.focalLength, A = std::fabs((double)s.apeture);
+    if (!(f > 0.0) || !std::isfinite(f) || !std::isfinite(A) || s.imageW < 2 || s.imageH < 2) return true;
+    const double u[3] = {s.cam_u[0], s.cam_u[1], s.cam_u[2]}, v[3] = {s.cam_v[0], s.cam_v[1], s.cam_v[2]}, w[3] = {s.cam_w[0], s.cam_w[1], s.cam_w[2]};
+    auto dot3 = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    // the argument needs an orthonormal camera frame (cudaCamera::Setup builds one); anything else: no culling
+    if (std::fabs(dot3(u, u) - 1.0) > 1e-3 || std::fabs(dot3(v, v) - 1.0) > 1e-3 || std::fabs(dot3(w, w) - 1.0) > 1e-3 ||
+        std::fabs(dot3(u, v)) > 1e-3 || std::fabs(dot3(u, w)) > 1e-3 || std::fabs(dot3(v, w)) > 1e-3) return true;
+    const double c[3] = {(double)l.disk.center.x - s.cam_pos[0], (double)l.disk.center.y - s.cam_pos[1], (double)l.disk.center.z - s.cam_pos[2]};
+    const double r = std::fabs((double)l.disk.radius) * 1.01 + 1e-3;
+    const double cx = dot3(c, u), cy = dot3(c, v), cz = -dot3(c, w);
+    if (!std::isfinite(cx) || !std::isfinite(cy) || !std::isfinite(cz) || !std::isfinite(r)) return true;
+    if (cz + r <= 0.0) return false;                                        // behind the lens plane: rays only go forward (dir . -w = f > 0)
+    const double z0 = cz - r > 0.0 ? cz - r : 0.0, z1 = cz + r;
+    const double k = std::fmax(std::fabs(1.0 - z0 / f), std::fabs(1.0 - z1 / f));
+    const double tanh_ = std::fabs((double)s.tanFovxOverTwo);
+    const double nx = (1.0 + 2.0 / ((double)s.imageW - 1.0)) * std::fabs((double)s.aspectRatio) * tanh_ * f;
+    const double ny = (1.0 + 2.0 / ((double)s.imageH - 1.0)) * tanh_ * f;
+    const double bx = (A * k + nx * z1 / f) * 1.01 + 1e-3, by = (A * k + ny * z1 / f) * 1.01 + 1e-3;
+    if (!std::isfinite(bx) || !std::isfinite(by)) return true;
+    return std::fabs(cx) - r <= bx && std::fabs(cy) - r <= by;
+}
+
 int add_lights_env(svr::DevScene& s)
 {
     s.env = nullptr;
@@ -314,9 +345,11 @@ int add_lights_env(svr::DevScene& s)
     s.env_offset[0] = g.env.offset.x; s.env_offset[1] = g.env.offset.y;
     s.env_on_escape = (uint32_t)g.opt_env_on_escape;
     s.num_lights = g.num_lights;
+    s.primary_light_mask = 0u;
     for (uint32_t i = 0; i < g.num_lights; ++i) {
         const svr_area_light& l = g.lights[i];
         svr::DevLight& d = s.lights[i];
+        if (!g.opt_light_cull || light_reachable_by_camera_rays(s, l)) s.primary_light_mask |= 1u << i;
         d.radius = l.disk.radius;
         d.center[0] = l.disk.center.x; d.center[1] = l.disk.center.y; d.center[2] = l.disk.center.z;
         d.normal[0] = l.disk.normal.x; d.normal[1] = l.disk.normal.y; d.normal[2] = l.disk.normal.z;
@@ -577,6 +610,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     cfg.blocks_per_cu = g.opt_blocks_per_cu > 0 ? g.opt_blocks_per_cu : 4;
     cfg.frames_log2 = g.opt_frames_log2;
     cfg.unit_override = g.opt_unit;
+    cfg.lm_straight = g.opt_local_majorant == 2;
     // The tile kernel folds the frames of a launch into the accumulator itself (running mean in frame order, 12 B per
     // pixel per launch, svr_trace_tile.hip); the scratch slots + k_resolve remain for frames traced AHEAD of the calls
     // that ask for them (their radiance is folded later, one frame per call) and for the other kernels.
@@ -625,7 +659,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         w.frame0 = first;
         w.nframes = n;
         w.fold = 1u;
-        w.queue = use_queue ? g.d_queue : nullptr;
+        w.queue = (use_queue || local_majorant) ? g.d_queue : nullptr;
         w.pend = (use_queue || local_majorant) ? g.d_pend : nullptr;
         w.queue_blocks = g.queue_blocks;
         int slot = -1;
@@ -813,6 +847,7 @@ void svr_shutdown(void)
     if (g.d_ticket) hipFree(g.d_ticket);
     if (g.d_queue) hipFree(g.d_queue);
     if (g.d_pend) hipFree(g.d_pend);
+    if (g_stage) { hipFree(g_stage); g_stage = nullptr; g_stage_floats = 0; }
     for (int i = 0; i < Context::EV_RING; ++i) {
         if (g.ev0[i]) hipEventDestroy(g.ev0[i]);
         if (g.ev1[i]) hipEventDestroy(g.ev1[i]);
@@ -863,7 +898,7 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
 {
     if (ensure_init()) return 0;
     if (!voxels || nx <= 0 || ny <= 0 || nz <= 0) { fail(-6, "svr_create_volume_texture: bad arguments (%p, %d, %d, %d)", (const void*)voxels, nx, ny, nz); return 0; }
-    if (layout != SVR_LAYOUT_AUTO && layout != SVR_LAYOUT_LINEAR && layout != SVR_LAYOUT_BRICK && layout != SVR_LAYOUT_PAIR) { fail(-6, "svr_create_volume_texture: unknown layout %d", layout); return 0; }
+    if (layout != SVR_LAYOUT_AUTO && layout != SVR_LAYOUT_LINEAR && layout != SVR_LAYOUT_BRICK && layout != SVR_LAYOUT_PAIR && layout != SVR_LAYOUT_CELL) { fail(-6, "svr_create_volume_texture: unknown layout %d", layout); return 0; }
     {
         // BRICK needs 24-bit brick-row / brick-slab strides (svr_trace_tile.hip); AUTO picks it when they fit
         size_t bx = ((size_t)nx + 2 * svr::VOL_PAD + svr::BRICK_X - 1) / svr::BRICK_X;
@@ -872,7 +907,10 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
         // PAIR: the same bricks with 32-bit elements -- strides and byte offsets double
         const size_t bz_ = ((size_t)nz + 2 * svr::VOL_PAD + svr::BRICK_Z - 1) / svr::BRICK_Z;
         const bool pair_ok = (bx * by * 512) < ((size_t)1 << 24) && bx * by * bz_ * 512 < ((size_t)1 << 32);
+        // CELL: 16-byte elements -- the element index uses 24-bit multiplies by the brick-row / brick-slab strides, the byte offset 32 bits
+        const bool cell_ok = (bx * by * 128) < ((size_t)1 << 24) && bx * by * bz_ * 128 * 16 < ((size_t)1 << 32);
         if (layout == SVR_LAYOUT_AUTO) layout = pair_ok ? SVR_LAYOUT_PAIR : (brick_ok ? SVR_LAYOUT_BRICK : SVR_LAYOUT_LINEAR);
+        if (layout == SVR_LAYOUT_CELL && !cell_ok) { fail(-6, "svr_create_volume_texture: %dx%dx%d is too large for the CELL layout (32-bit byte offsets of 16-byte elements); use PAIR or BRICK", nx, ny, nz); return 0; }
         if (layout == SVR_LAYOUT_PAIR && !pair_ok) { fail(-6, "svr_create_volume_texture: %dx%dx%d is too large for the PAIR layout (32-bit byte offsets); use BRICK", nx, ny, nz); return 0; }
         if (layout == SVR_LAYOUT_BRICK && !brick_ok) { fail(-6, "svr_create_volume_texture: %dx%d slices are too large for the BRICK layout; use LINEAR", nx, ny); return 0; }
     }
@@ -888,7 +926,7 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
         t->bnx = (int)bx; t->bny = (int)by; t->sy = 0; t->sz = 0;
         elems = bx * by * bz * (size_t)(svr::BRICK_X * svr::BRICK_Y * svr::BRICK_Z);
     }
-    if (elems >= ((size_t)1 << 31)) { delete t; fail(-6, "svr_create_volume_texture: %zu padded voxels exceed 32-bit byte offsets", elems); return 0; }
+    if (elems >= ((size_t)1 << 31) || (layout == SVR_LAYOUT_CELL && elems >= ((size_t)1 << 28))) { delete t; fail(-6, "svr_create_volume_texture: %zu padded voxels exceed 32-bit byte offsets", elems); return 0; }
     // macro-cell grid for empty-space skipping: smallest cell size whose bitmask fits MASK_WORDS_MAX words
     {
         int sh = 0;
@@ -897,7 +935,7 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
             if (gx * gy * gz <= (size_t)svr::MASK_WORDS_MAX * 32) { t->mc_shift = sh; t->mc_gx = (int)gx; t->mc_gy = (int)gy; t->mc_gz = (int)gz; break; }
         }
     }
-    t->bytes = elems * (layout == SVR_LAYOUT_PAIR ? sizeof(uint32_t) : sizeof(uint16_t));
+    t->bytes = elems * (layout == SVR_LAYOUT_CELL ? 16u : (layout == SVR_LAYOUT_PAIR ? sizeof(uint32_t) : sizeof(uint16_t)));
     size_t src_bytes = (size_t)nx * ny * nz * sizeof(uint16_t);
     const uint16_t* d_src = voxels;
     uint16_t* staged = nullptr;
@@ -909,7 +947,7 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
         d_src = staged;
     }
     e = hipMalloc(&t->data, t->bytes);
-    if (e == hipSuccess) e = hipMemsetAsync(t->data, 0, t->bytes, g.stream);
+    if (e == hipSuccess && layout != SVR_LAYOUT_CELL) e = hipMemsetAsync(t->data, 0, t->bytes, g.stream);      // (the CELL repack writes every element)
     if (e == hipSuccess) e = svr::launch_repack(d_src, (uint16_t*)t->data, nx, ny, nz, layout, t->sy, t->sz, t->bnx, t->bny, g.stream);
     if (e == hipSuccess) e = hipMalloc((void**)&t->mm, (size_t)t->mc_gx * t->mc_gy * t->mc_gz * 2 * sizeof(uint16_t));
     if (e == hipSuccess) e = svr::launch_minmax(d_src, t->mm, nx, ny, nz, t->mc_shift, t->mc_gx, t->mc_gy, t->mc_gz, g.stream);
@@ -1161,6 +1199,126 @@ int svr_set_row_shard(uint32_t strip_rows, uint32_t rank, uint32_t world)
     return 0;
 }
 
+// ---------------- frame assembly (native counterpart of sunvolumerender_amd/dist.py) ----------------
+uint32_t svr_strip_rows_owned(uint32_t H, uint32_t strip_rows, uint32_t rank, uint32_t world)
+{
+    if (world <= 1 || strip_rows == 0) return rank == 0 || world <= 1 ? H : 0;
+    if (rank >= world) return 0;
+    uint32_t rows = 0;
+    const uint32_t nstrips = (H + strip_rows - 1) / strip_rows;
+    for (uint32_t sidx = rank; sidx < nstrips; sidx += world) {
+        const uint32_t ys = sidx * strip_rows, ye = ys + strip_rows < H ? ys + strip_rows : H;
+        rows += ye - ys;
+    }
+    return rows;
+}
+
+uint32_t svr_strip_row_to_y(uint32_t p, uint32_t H, uint32_t strip_rows, uint32_t rank, uint32_t world)
+{
+    if (p >= svr_strip_rows_owned(H, strip_rows, rank, world)) return 0xffffffffu;
+    if (world <= 1 || strip_rows == 0) return p;
+    const uint32_t q = p / strip_rows;
+    return (q * world + rank) * strip_rows + (p - q * strip_rows);
+}
+
+static int strips_call(void* packed, void* frame, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t rank, uint32_t world, int to_packed, const char* who)
+{
+    if (ensure_init()) return g.err_code;
+    if (!packed || !frame || W == 0 || H == 0) return fail(-4, "%s: bad argument", who);
+    if (world > 1 && (rank >= world || strip_rows == 0)) return fail(-6, "%s: rank %u of %u, strip_rows %u", who, rank, world, strip_rows);
+    HIP_TRY(svr::launch_strips((float*)packed, (float*)frame, 3u * W, svr_strip_rows_owned(H, strip_rows, rank, world), strip_rows, rank, world, to_packed, g.stream));
+    return 0;
+}
+int svr_pack_strips(void* packed, const void* hdr, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t rank, uint32_t world)
+{
+    return strips_call(packed, const_cast<void*>(hdr), W, H, strip_rows, rank, world, 1, "svr_pack_strips");
+}
+int svr_unpack_strips(void* frame, const void* packed, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t rank, uint32_t world)
+{
+    return strips_call(const_cast<void*>(packed), frame, W, H, strip_rows, rank, world, 0, "svr_unpack_strips");
+}
+
+namespace {
+// the four RCCL entry points of the exchange, resolved from the RCCL the process has loaded (rccl.h: ncclResult_t is an int, 0 = success)
+struct Rccl {
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    bool tried = false;
+} g_rccl;
+constexpr int RCCL_FLOAT32 = 7;                          // ncclFloat32
+bool rccl_resolve()
+{
+    if (!g_rccl.tried) {
+        g_rccl.tried = true;
+        void* h = nullptr;
+        for (const char* name : {"librccl.so", "librccl.so.1", "libnccl.so", "libnccl.so.2"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        if (h) {
+            g_rccl.group_start = (int (*)())dlsym(h, "ncclGroupStart");
+            g_rccl.group_end = (int (*)())dlsym(h, "ncclGroupEnd");
+            g_rccl.send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+            g_rccl.recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+        }
+    }
+    return g_rccl.group_start && g_rccl.group_end && g_rccl.send && g_rccl.recv;
+}
+}
+
+int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_local, uint32_t W, uint32_t H,
+                       uint32_t strip_rows, uint32_t rank, uint32_t world, uint32_t root)
+{
+    if (ensure_init()) return g.err_code;
+    if (!hdr_local || W == 0 || H == 0 || world == 0 || rank >= world || root >= world) return fail(-4, "svr_assemble_frame: bad argument");
+    if (rank == root && !frame_on_root) return fail(-4, "svr_assemble_frame: frame_on_root is null on the root rank");
+    const size_t row = (size_t)3 * W;
+    if (world == 1) {
+        HIP_TRY(hipMemcpyAsync(frame_on_root, hdr_local, row * H * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+        return 0;
+    }
+    if (!nccl_comm) return fail(-4, "svr_assemble_frame: nccl_comm is null");
+    if (strip_rows == 0) return fail(-6, "svr_assemble_frame: strip_rows is 0");
+    if (!rccl_resolve()) return fail(-7, "svr_assemble_frame: no RCCL in this process (dlopen(\"librccl.so\") / ncclSend / ncclRecv not found)");
+    // staging: on root the packed rows of every rank back to back (= one frame), elsewhere this rank's rows
+    const size_t need = rank == root ? row * H : row * svr_strip_rows_owned(H, strip_rows, rank, world);
+    if (need > g_stage_floats) {
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (g_stage) HIP_TRY(hipFree(g_stage));
+        g_stage = nullptr; g_stage_floats = 0;
+        HIP_TRY(hipMalloc((void**)&g_stage, need * sizeof(float)));
+        g_stage_floats = need;
+    }
+    if (rank != root) {
+        const uint32_t mine = svr_strip_rows_owned(H, strip_rows, rank, world);
+        if (svr_pack_strips(g_stage, hdr_local, W, H, strip_rows, rank, world)) return g.err_code;
+        if (mine) {
+            const int rc = g_rccl.send(g_stage, row * mine, RCCL_FLOAT32, (int)root, nccl_comm, g.stream);
+            if (rc != 0) return fail(-7, "svr_assemble_frame: ncclSend failed (%d)", rc);
+        }
+        return 0;
+    }
+    // root: its own rows straight into the frame, the peers' rows through the staging buffer
+    if (frame_on_root != hdr_local) {
+        if (svr_pack_strips(g_stage, hdr_local, W, H, strip_rows, rank, world)) return g.err_code;
+        if (svr_unpack_strips(frame_on_root, g_stage, W, H, strip_rows, rank, world)) return g.err_code;
+    }
+    int rc = g_rccl.group_start();
+    size_t off = 0;
+    std::vector<size_t> offs(world, 0);
+    for (uint32_t r = 0; r < world && rc == 0; ++r) {
+        const uint32_t n = svr_strip_rows_owned(H, strip_rows, r, world);
+        offs[r] = off;
+        if (r != root && n) rc = g_rccl.recv(g_stage + off, row * n, RCCL_FLOAT32, (int)r, nccl_comm, g.stream);
+        off += row * n;
+    }
+    const int rc2 = g_rccl.group_end();
+    if (rc != 0 || rc2 != 0) return fail(-7, "svr_assemble_frame: ncclRecv failed (%d, %d)", rc, rc2);
+    for (uint32_t r = 0; r < world; ++r)
+        if (r != root && svr_unpack_strips(frame_on_root, g_stage + offs[r], W, H, strip_rows, r, world)) return g.err_code;
+    return 0;
+}
+
 int svr_set_render_window(int x0, int y0, int x1, int y1)
 {
     g.wx0 = x0; g.wy0 = y0; g.wx1 = x1; g.wy1 = y1;
@@ -1195,7 +1353,10 @@ int svr_set_option(int key, int value)
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_FINE_MASK: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_fine_mask = value; return 0;
     case SVR_OPT_FAST_MATH: g.opt_fast_math = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
-    case SVR_OPT_LOCAL_MAJORANT: g.opt_local_majorant = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
+    case SVR_OPT_LIGHT_CULL: g.opt_light_cull = value ? 1 : 0; return 0;
+    case SVR_OPT_LOCAL_MAJORANT:
+        if (value < 0 || value > 2) return fail(-6, "SVR_OPT_LOCAL_MAJORANT: bad value %d (0 off, 1 on, 2 on with straight-line paths only)", value);
+        g.opt_local_majorant = value; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_QUEUE:
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_QUEUE: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_queue = value; g.queue_alloc_failed = false; return 0;
@@ -1240,6 +1401,7 @@ int svr_get_option(int key)
     case SVR_OPT_FINE_MASK: return g.opt_fine_mask;
     case SVR_OPT_FAST_MATH: return g.opt_fast_math;
     case SVR_OPT_LOCAL_MAJORANT: return g.opt_local_majorant;
+    case SVR_OPT_LIGHT_CULL: return g.opt_light_cull;
     case SVR_OPT_QUEUE: return g.opt_queue;
     case SVR_OPT_PARK_END: return g.opt_park_end;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;

@@ -131,6 +131,16 @@ SVR_DEV float tex3d(const DevScene& s, float u, float v, float w)
         v010 = (float)p1[0]; v110 = (float)p1[1];
         v001 = (float)p2[0]; v101 = (float)p2[1];
         v011 = (float)p3[0]; v111 = (float)p3[1];
+    } else if (LAYOUT == LAYOUT_CELL) {
+        // 16-byte elements: the 8 voxels of the cell (svr_walk.hpp, tex_fetch)
+        const uint32_t ui = (uint32_t)i, uj = (uint32_t)j, uk = (uint32_t)k;
+        const uint32_t e = (((ui >> 3) << 7) + (ui & 7u)) + ((uj >> 2) * ((uint32_t)s.bnx << 7) + ((uj & 3u) << 3)) +
+                           ((uk >> 2) * ((uint32_t)(s.bny * s.bnx) << 7) + ((uk & 3u) << 5));
+        const uint4 c4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(vox) + ((size_t)e << 4));
+        v000 = (float)(c4.x & 0xffffu); v100 = (float)(c4.x >> 16);
+        v010 = (float)(c4.y & 0xffffu); v110 = (float)(c4.y >> 16);
+        v001 = (float)(c4.z & 0xffffu); v101 = (float)(c4.z >> 16);
+        v011 = (float)(c4.w & 0xffffu); v111 = (float)(c4.w >> 16);
     } else if (LAYOUT == LAYOUT_PAIR) {
         // 32-bit elements: voxel x | voxel x + 1 << 16 (svr_walk.hpp, tex_fetch)
         int j1 = j + 1, k1 = k + 1;
@@ -374,6 +384,8 @@ SVR_DEV int nearest_light(const DevScene& s, v3 orig, v3 dir, float& tHit)
     float t = SVR_FLT_MAX;
     int id = -1;
     for (uint32_t i = 0; i < s.num_lights; ++i) {
+        // (lights no camera ray can reach -- outside the view frustum, lens included: svr_api.hip -- cannot change the result)
+        if (!((s.primary_light_mask >> i) & 1u)) continue;
         if (disk_intersect(s.lights[i], orig, dir, t) && (t < tNear)) {
             tNear = t;
             id = (int)i;

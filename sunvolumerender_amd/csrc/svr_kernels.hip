@@ -529,6 +529,8 @@ static hipError_t launch_pathtrace_t(const DevScene& s, const DevWork& w, const 
 
 hipError_t launch_pathtrace(const DevScene& s, const DevWork& w, const LaunchCfg& cfg, hipStream_t st)
 {
+    if (s.layout == LAYOUT_CELL)
+        return cfg.count ? launch_pathtrace_t<LAYOUT_CELL, true>(s, w, cfg, st) : launch_pathtrace_t<LAYOUT_CELL, false>(s, w, cfg, st);
     if (s.layout == LAYOUT_PAIR)
         return cfg.count ? launch_pathtrace_t<LAYOUT_PAIR, true>(s, w, cfg, st) : launch_pathtrace_t<LAYOUT_PAIR, false>(s, w, cfg, st);
     if (s.layout == LAYOUT_LINEAR)
@@ -552,9 +554,61 @@ hipError_t launch_tonemap(const DevScene& s, const DevWork& w, hipStream_t st)
     return hipGetLastError();
 }
 
+// CELL layout: element (i, j, k) of the padded brick grid = the 8 voxels of the trilinear cell whose lowest corner is voxel
+// (i, j, k) - VOL_PAD, as four PAIR words (x | x + 1 << 16) for (y, z), (y + 1, z), (y, z + 1), (y + 1, z + 1); voxels outside the
+// volume are border texels = 0.  Every element of the grid is written (no zero fill needed).
+__global__ __launch_bounds__(256) void k_repack_cell(const uint16_t* __restrict__ src, uint4* __restrict__ dst, int nx, int ny, int nz, int bnx, int bny, int bnz)
+{
+    const size_t n = (size_t)bnx * bny * bnz * 128u;
+    for (size_t e = (size_t)blockIdx.x * 256u + threadIdx.x; e < n; e += (size_t)gridDim.x * 256u) {
+        const size_t brick = e >> 7;
+        const uint32_t in = (uint32_t)(e & 127u);
+        const int bi = (int)(brick % (size_t)bnx), bj = (int)((brick / (size_t)bnx) % (size_t)bny), bk = (int)(brick / ((size_t)bnx * bny));
+        const int x = (bi << 3) + (int)(in & 7u) - VOL_PAD, y = (bj << 2) + (int)((in >> 3) & 3u) - VOL_PAD, z = (bk << 2) + (int)(in >> 5) - VOL_PAD;
+        auto vox = [&](int xx, int yy, int zz) -> uint32_t {
+            return (xx >= 0 && yy >= 0 && zz >= 0 && xx < nx && yy < ny && zz < nz) ? (uint32_t)src[((size_t)zz * ny + yy) * nx + xx] : 0u;
+        };
+        uint4 c;
+        c.x = vox(x, y, z) | (vox(x + 1, y, z) << 16);
+        c.y = vox(x, y + 1, z) | (vox(x + 1, y + 1, z) << 16);
+        c.z = vox(x, y, z + 1) | (vox(x + 1, y, z + 1) << 16);
+        c.w = vox(x, y + 1, z + 1) | (vox(x + 1, y + 1, z + 1) << 16);
+        dst[e] = c;
+    }
+}
+
+// frame assembly of row-sharded renders (svr_assemble_frame): the p-th owned row of `rank` is row (q * world + rank) * strip + p % strip, q = p / strip
+__global__ __launch_bounds__(256) void k_strips(float* __restrict__ packed, float* __restrict__ frame, uint32_t row_floats, uint32_t n_rows,
+                                                uint32_t strip_rows, uint32_t rank, uint32_t world, int to_packed)
+{
+    const size_t n = (size_t)n_rows * row_floats;
+    for (size_t e = (size_t)blockIdx.x * 256u + threadIdx.x; e < n; e += (size_t)gridDim.x * 256u) {
+        const uint32_t p = (uint32_t)(e / row_floats), col = (uint32_t)(e - (size_t)p * row_floats);
+        const uint32_t q = p / strip_rows;
+        const uint32_t y = world <= 1u ? p : (q * world + rank) * strip_rows + (p - q * strip_rows);
+        const size_t f = (size_t)y * row_floats + col;
+        if (to_packed) packed[e] = frame[f]; else frame[f] = packed[e];
+    }
+}
+
+hipError_t launch_strips(float* packed, float* frame, uint32_t row_floats, uint32_t n_rows, uint32_t strip_rows, uint32_t rank, uint32_t world,
+                         int to_packed, hipStream_t st)
+{
+    if (n_rows == 0 || row_floats == 0) return hipSuccess;
+    const size_t n = (size_t)n_rows * row_floats;
+    const uint32_t blocks = (uint32_t)((n + 255u) / 256u < 4096u ? (n + 255u) / 256u : 4096u);
+    hipLaunchKernelGGL(k_strips, dim3(blocks), dim3(256), 0, st, packed, frame, row_floats, n_rows, strip_rows ? strip_rows : 1u, rank, world, to_packed);
+    return hipGetLastError();
+}
+
 hipError_t launch_repack(const uint16_t* src, uint16_t* dst, int nx, int ny, int nz, int layout,
                          int sy, int sz, int bnx, int bny, hipStream_t st)
 {
+    if (layout == LAYOUT_CELL) {
+        const int bnz = (nz + 2 * VOL_PAD + BRICK_Z - 1) / BRICK_Z;
+        hipLaunchKernelGGL(k_repack_cell, dim3(8192), dim3(256), 0, st, src, reinterpret_cast<uint4*>(dst), nx, ny, nz, bnx, bny, bnz);
+        return hipGetLastError();
+    }
     if (layout == LAYOUT_PAIR) {
         hipLaunchKernelGGL(k_repack_pair, dim3(4096), dim3(256), 0, st, src, reinterpret_cast<uint32_t*>(dst), nx, ny, nz, bnx, bny);
         return hipGetLastError();

@@ -46,6 +46,7 @@ struct LaunchCfg {
     int blocks_per_cu;     // persistent kernel
     int unit_override;     // tile kernel: tasks per ticket (0 = heuristic)
     int frames_log2;       // tile kernel: log2(frames per wave), -1 = as many as the group allows (<= 8)
+    bool lm_straight;      // local-majorant kernel: straight-line paths also where the pool form applies (cross-check)
 };
 
 // trace work.nframes paths per owned pixel into the scratch slots work.lbuf
@@ -74,6 +75,9 @@ hipError_t launch_fine_mask(const uint16_t* mm, uint32_t n_cells, const uint32_t
 // bound classes of the half-resolution macro-cells (4 bit each) + the BOUND_CLASSES thresholds, into accel + ACCEL_CLASS_OFF
 hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const float* tf_rgba, int tf_n, float densityScale,
                               float invSigmaMax, uint32_t* accel, hipStream_t stream);
+// rows of one rank of a row-strip shard: packed (n_rows x row_floats) <-> full frame; to_packed: 1 = pack, 0 = unpack
+hipError_t launch_strips(float* packed, float* frame, uint32_t row_floats, uint32_t n_rows, uint32_t strip_rows, uint32_t rank, uint32_t world,
+                         int to_packed, hipStream_t stream);
 // hdr_to_ldr over the owned pixels
 hipError_t launch_tonemap(const DevScene& scene, const DevWork& work, hipStream_t stream);
 // self-test of the ray caster's sample-chain replay (tests only): in = (t, h, bound, n) per item

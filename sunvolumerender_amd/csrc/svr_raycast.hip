@@ -386,7 +386,10 @@ hipError_t launch_raycast(const DevScene& s, const DevWork& w, float stepSize, b
     if (e != hipSuccess) return e;
     const uint32_t max_blocks = (uint32_t)num_cus;                       // one 1024-thread block (16 waves, 96 KB LDS) per CU
     const bool skip = s.empty_mask != nullptr;
-    if (s.layout == LAYOUT_PAIR) {
+    if (s.layout == LAYOUT_CELL) {
+        if (count) { if (skip) launch_s<LAYOUT_CELL, true, true>(s, w, stepSize, lanes_log2, max_blocks, st); else launch_s<LAYOUT_CELL, true, false>(s, w, stepSize, lanes_log2, max_blocks, st); }
+        else { if (skip) launch_s<LAYOUT_CELL, false, true>(s, w, stepSize, lanes_log2, max_blocks, st); else launch_s<LAYOUT_CELL, false, false>(s, w, stepSize, lanes_log2, max_blocks, st); }
+    } else if (s.layout == LAYOUT_PAIR) {
         if (count) { if (skip) launch_s<LAYOUT_PAIR, true, true>(s, w, stepSize, lanes_log2, max_blocks, st); else launch_s<LAYOUT_PAIR, true, false>(s, w, stepSize, lanes_log2, max_blocks, st); }
         else { if (skip) launch_s<LAYOUT_PAIR, false, true>(s, w, stepSize, lanes_log2, max_blocks, st); else launch_s<LAYOUT_PAIR, false, false>(s, w, stepSize, lanes_log2, max_blocks, st); }
     } else if (s.layout == LAYOUT_LINEAR) {

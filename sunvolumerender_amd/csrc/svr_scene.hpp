@@ -8,7 +8,7 @@
 namespace svr {
 
 // volume memory layouts (software "texture"; gfx950 exposes no image/sampler path to HIP)
-enum { LAYOUT_LINEAR = 1, LAYOUT_BRICK = 2, LAYOUT_PAIR = 3 };   // PAIR: BRICK with 32-bit elements (voxel x | voxel x + 1 << 16)
+enum { LAYOUT_LINEAR = 1, LAYOUT_BRICK = 2, LAYOUT_PAIR = 3, LAYOUT_CELL = 4 };   // PAIR: BRICK with 32-bit elements (voxel x | voxel x + 1 << 16); CELL: 16-byte elements = the 8 voxels of a trilinear cell
 constexpr int VOL_PAD = 2;         // zero apron, voxels, each side (border addressing)
 constexpr int BRICK_X = 8, BRICK_Y = 4, BRICK_Z = 4;   // 8*4*4 u16 = 256 B
 
@@ -74,6 +74,7 @@ struct DevScene {
     uint32_t env_on_escape;
     // ---- area lights ----
     uint32_t num_lights;
+    uint32_t primary_light_mask;   // bit i: a camera ray can reach light i (host-side conservative frustum test); the others are skipped in the nearest-light test
     DevLight lights[8];
 };
 

@@ -36,69 +36,184 @@ SVR_DEV void class_bound(uint32_t cl, float& b, float& rb)
     rb = u2f(((uint32_t)(127 - e - (int)odd) << 23) | man);
 }
 
+// The grid a walk steps through (wave-uniform).  Scenes with exactly transparent space walk the FULL-resolution macro grid:
+// a macro-cell whose `empty` bit is set has bound 0, any other the bound class of its half-resolution parent -- half the
+// wasted tentative collisions in the cells that straddle a surface, and a walk may start anywhere in the empty space in
+// front of the first occupied macro-cell with the same result (see lm_begin).  Scenes without (noisy air: c3n) walk the
+// half-resolution grid of the classes themselves: half the steps.
+struct LmGrid { float sc; int gx, gy, gz, sy, sz; bool fine; };
+SVR_DEV LmGrid lm_grid(const DevScene& s)
+{
+    LmGrid g;
+    g.fine = s.has_empty != 0u;
+    g.sc = g.fine ? 1.f : 0.5f;
+    g.gx = g.fine ? s.mc_gx : s.mc_hgx;
+    g.gy = g.fine ? s.mc_gy : (s.mc_gy + 1) >> 1;
+    g.gz = g.fine ? s.mc_gz : (s.mc_gz + 1) >> 1;
+    g.sy = g.gx;
+    g.sz = g.fine ? s.mc_gxy : s.mc_hgxy;
+    return g;
+}
+
+// a walk in flight: grid coordinate = A + t / r per axis; (tx, ty, tz) = ray parameter of the next cell boundary per axis
+struct LmWalk {
+    float t, tMax, S, tx, ty, tz, Ax, Ay, Az, rx, ry, rz, b, rb;
+    int ix, iy, iz, q;
+};
+
+// cell of the point at ray parameter t, and the (absolute) ray parameters of its far boundaries
+SVR_DEV void lm_locate(const LmGrid& g, LmWalk& w, float t)
+{
+    const float INF = u2f(SVR_INF_BITS);
+    // grid coordinate = A + t / r (r = 1 / B; an axis the ray does not move along has r = +-inf and a boundary at infinity)
+    const float Bx = __builtin_amdgcn_rcpf(w.rx), By = __builtin_amdgcn_rcpf(w.ry), Bz = __builtin_amdgcn_rcpf(w.rz);
+    w.ix = min(max((int)__builtin_floorf(fma_(Bx, t, w.Ax)), 0), g.gx - 1);
+    w.iy = min(max((int)__builtin_floorf(fma_(By, t, w.Ay)), 0), g.gy - 1);
+    w.iz = min(max((int)__builtin_floorf(fma_(Bz, t, w.Az)), 0), g.gz - 1);
+    w.tx = Bx != 0.f ? ((float)(w.ix + (Bx > 0.f ? 1 : 0)) - w.Ax) * w.rx : INF;
+    w.ty = By != 0.f ? ((float)(w.iy + (By > 0.f ? 1 : 0)) - w.Ay) * w.ry : INF;
+    w.tz = Bz != 0.f ? ((float)(w.iz + (Bz > 0.f ? 1 : 0)) - w.Az) * w.rz : INF;
+    w.q = w.ix + w.iy * g.sy + w.iz * g.sz;
+}
+
+// Start a walk along (o, d) at t0.  Cell boundaries are ABSOLUTE -- functions of the integer cell index, never accumulated --
+// so a walk that starts at any t0 of the empty space in front of its first occupied cell spends its free path exactly as
+// one started at the box entry: the shared and the per-lane whole-ray tests (which return different, equally valid t0)
+// give the same bits, and a frame's radiance stays a pure function of (scene, pixel, frame) in this mode too.
+SVR_DEV void lm_begin(const DevScene& s, const LmGrid& g, LmWalk& w, v3 o, v3 d, float t0, float tMax, Rng& rng)
+{
+    w.Ax = g.sc * fma_(o.x - s.vmin[0], s.mc_scale[0], s.mc_off);
+    w.Ay = g.sc * fma_(o.y - s.vmin[1], s.mc_scale[1], s.mc_off);
+    w.Az = g.sc * fma_(o.z - s.vmin[2], s.mc_scale[2], s.mc_off);
+    const float Bx = g.sc * (d.x * s.mc_scale[0]), By = g.sc * (d.y * s.mc_scale[1]), Bz = g.sc * (d.z * s.mc_scale[2]);
+    const float INF = u2f(SVR_INF_BITS);
+    w.rx = Bx != 0.f ? __builtin_amdgcn_rcpf(Bx) : INF; w.ry = By != 0.f ? __builtin_amdgcn_rcpf(By) : INF; w.rz = Bz != 0.f ? __builtin_amdgcn_rcpf(Bz) : INF;
+    w.t = t0; w.tMax = tMax;
+    w.ix = min(max((int)__builtin_floorf(fma_(Bx, t0, w.Ax)), 0), g.gx - 1);
+    w.iy = min(max((int)__builtin_floorf(fma_(By, t0, w.Ay)), 0), g.gy - 1);
+    w.iz = min(max((int)__builtin_floorf(fma_(Bz, t0, w.Az)), 0), g.gz - 1);
+    w.tx = Bx != 0.f ? ((float)(w.ix + (Bx > 0.f ? 1 : 0)) - w.Ax) * w.rx : INF;
+    w.ty = By != 0.f ? ((float)(w.iy + (By > 0.f ? 1 : 0)) - w.Ay) * w.ry : INF;
+    w.tz = Bz != 0.f ? ((float)(w.iz + (Bz > 0.f ? 1 : 0)) - w.Az) * w.rz : INF;
+    w.q = w.ix + w.iy * g.sy + w.iz * g.sz;
+    w.b = 1.f; w.rb = 1.f;
+    // free path at the global majorant (woodcock_tracking.h:34); a cell of bound b spends it at rate b
+    w.S = -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+}
+
+// One cell of the DDA.  0 = moved on to the next cell, 1 = tentative collision at w.t (the free path ran out in this cell),
+// 2 = the walk has left the box.
+template <bool COUNT, typename LDS>
+SVR_DEV int lm_step(const DevScene& s, const LDS& L, const LmGrid& g, LmWalk& w, Cnt& c)
+{
+    const float te = fmin_(fmin_(w.tx, w.ty), fmin_(w.tz, w.tMax));
+    if (COUNT) c.ipre++;
+    uint32_t cl;
+    if (g.fine) {
+        const bool empty = (L.emask[(uint32_t)w.q >> 5] >> ((uint32_t)w.q & 31u)) & 1u;
+        const uint32_t hq = (uint32_t)((w.ix >> 1) + (w.iy >> 1) * s.mc_hgx + (w.iz >> 1) * s.mc_hgxy);
+        cl = 0u;
+        if (!empty) cl = (L.cls[hq >> 3] >> ((hq & 7u) << 2)) & 15u;
+        else {
+            // Empty space: no free path is spent, so the walk may LEAP.  Every macro-cell within Chebyshev distance dd - 1 of this
+            // one is empty (distance field, svr_accel.hip): the ray may advance until its largest-axis displacement is dd - 1
+            // cells (first_occupied's sphere tracing, svr_walk.hpp) and pick up the DDA in the cell it lands in.  Boundaries are
+            // absolute, so where exactly a leap lands does not change what follows.
+            const uint32_t dd = (L.dist[hq >> 3] >> ((hq & 7u) << 2)) & 15u;
+            if (dd >= 4u) {
+                const float inv = fmin_(__builtin_fabsf(w.rx), fmin_(__builtin_fabsf(w.ry), __builtin_fabsf(w.rz))) * 0.999f;      // 1 / largest |B|
+                const float tl = fma_((float)dd - 1.05f, inv, w.t);
+                if (tl >= w.tMax) return 2;
+                if (tl > te) { w.t = tl; lm_locate(g, w, tl); return 0; }
+            }
+        }
+    } else
+        cl = (L.cls[(uint32_t)w.q >> 3] >> (((uint32_t)w.q & 7u) << 2)) & 15u;
+    if (cl != 0u) {
+        class_bound(cl, w.b, w.rb);
+        const float room = (te - w.t) * w.b;                     // (<= 0 for the part of a cell behind the start of the walk)
+        if (w.S <= room) { w.t = fma_(w.S, w.rb, w.t); return 1; }
+        w.S -= fmax_(room, 0.f);
+    }
+    if (te >= w.tMax) return 2;
+    w.t = fmax_(te, w.t);
+    // The LAST cell of an axis also holds what lies beyond it (svr_accel.hip: its bound covers the trilinear cell N - 1, the
+    // half voxel between the last voxel centre and the box face): a walk that crosses the grid's upper end stays in that cell
+    // until it leaves the box.  (Below 0 there is nothing: the box starts inside cell 0.)
+    const float INF = u2f(SVR_INF_BITS);
+    if (w.tx <= w.ty && w.tx <= w.tz) {
+        const int sx = w.rx > 0.f ? 1 : -1;
+        if (w.ix + sx >= g.gx) w.tx = INF;
+        else {
+            w.ix += sx; w.q += sx;
+            if (w.ix < 0) return 2;
+            w.tx = ((float)(w.ix + (sx > 0 ? 1 : 0)) - w.Ax) * w.rx;
+        }
+    } else if (w.ty <= w.tz) {
+        const int sy = w.ry > 0.f ? 1 : -1;
+        if (w.iy + sy >= g.gy) w.ty = INF;
+        else {
+            w.iy += sy; w.q += sy * g.sy;
+            if (w.iy < 0) return 2;
+            w.ty = ((float)(w.iy + (sy > 0 ? 1 : 0)) - w.Ay) * w.ry;
+        }
+    } else {
+        const int sz = w.rz > 0.f ? 1 : -1;
+        if (w.iz + sz >= g.gz) w.tz = INF;
+        else {
+            w.iz += sz; w.q += sz * g.sz;
+            if (w.iz < 0) return 2;
+            w.tz = ((float)(w.iz + (sz > 0 ? 1 : 0)) - w.Az) * w.rz;
+        }
+    }
+    return 0;
+}
+
+// The tentative collision at w.t: fetch, accept with the reference's probability (woodcock_tracking.h:43) over the local
+// majorant's share b of sigma_max.  true = collision (val = the fetched intensity); false = the next free path is drawn.
+template <int LAYOUT, bool COUNT, typename LDS>
+SVR_DEV bool lm_tentative(const DevScene& s, const LDS& L, const LmGrid& g, LmWalk& w, v3 o, v3 d, Rng& rng, float& val, Cnt& c)
+{
+    if (COUNT) c.iters++;
+    const Cell cell = cell_of(s, o + d * w.t);
+    bool fetch = true;
+    if (!g.fine && s.has_empty) fetch = !cell_is_empty<false>(L, s, cell);       // (the fine grid has the `empty` bit in its bounds already)
+    if (fetch) {
+        if (COUNT) { c.exec++; c.taps++; }
+        val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
+        const float ratio = alpha_of(L, s, val) * s.invSigmaMax;
+        if (rng_uniform(rng) * w.b < ratio) return true;
+    }
+    w.S = -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+    return false;
+}
+
 // sample_distance (woodcock_tracking.h:20-51) against the local majorants, from ray parameter t0 (>= the reference's
-// tMin) to tMax: the collision's t, or -FLT_MAX.  val = the intensity fetched at the collision (pathtracer.cu:241).
+// tMin, in the empty space in front of the first occupied cell) to tMax: the collision's t, or -FLT_MAX.  val = the
+// intensity fetched at the collision (pathtracer.cu:241).
 template <int LAYOUT, bool COUNT, typename LDS>
 SVR_DEV float walk_lm(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float t0, float tMax, float& val, Cnt& c)
 {
-    const float INF = u2f(SVR_INF_BITS);
-    // half-resolution macro grid: h(t) = A + B t per axis, cell = floor(h)
-    const float Ax = 0.5f * fma_(orig.x - s.vmin[0], s.mc_scale[0], s.mc_off), Bx = 0.5f * (dir.x * s.mc_scale[0]);
-    const float Ay = 0.5f * fma_(orig.y - s.vmin[1], s.mc_scale[1], s.mc_off), By = 0.5f * (dir.y * s.mc_scale[1]);
-    const float Az = 0.5f * fma_(orig.z - s.vmin[2], s.mc_scale[2], s.mc_off), Bz = 0.5f * (dir.z * s.mc_scale[2]);
-    const int hgx = s.mc_hgx, hgy = (s.mc_gy + 1) >> 1, hgz = (s.mc_gz + 1) >> 1;
-    float t = t0;
-    int ix = min(max((int)__builtin_floorf(fma_(Bx, t, Ax)), 0), hgx - 1);
-    int iy = min(max((int)__builtin_floorf(fma_(By, t, Ay)), 0), hgy - 1);
-    int iz = min(max((int)__builtin_floorf(fma_(Bz, t, Az)), 0), hgz - 1);
-    // ray parameter of the next cell boundary per axis, and between boundaries
-    const float rx = __builtin_amdgcn_rcpf(Bx), ry = __builtin_amdgcn_rcpf(By), rz = __builtin_amdgcn_rcpf(Bz);
-    float tx = Bx != 0.f ? fmax_(((float)(ix + (Bx > 0.f ? 1 : 0)) - Ax) * rx, t) : INF;
-    float ty = By != 0.f ? fmax_(((float)(iy + (By > 0.f ? 1 : 0)) - Ay) * ry, t) : INF;
-    float tz = Bz != 0.f ? fmax_(((float)(iz + (Bz > 0.f ? 1 : 0)) - Az) * rz, t) : INF;
-    const float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
-    const int sx = Bx > 0.f ? 1 : -1, sy = By > 0.f ? 1 : -1, sz = Bz > 0.f ? 1 : -1;
-    const int qsy = sy * hgx, qsz = sz * (int)s.mc_hgxy;
-    int q = ix + iy * hgx + iz * (int)s.mc_hgxy;
-    // free path at the global majorant (woodcock_tracking.h:34); a cell of bound b spends it at rate b
-    float S = -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
-    float b = 1.f, rb = 1.f;
+    const LmGrid g = lm_grid(s);
+    LmWalk w;
+    lm_begin(s, g, w, orig, dir, t0, tMax, rng);
     for (uint32_t guard = 0; guard < SVR_WALK_GUARD; ++guard) {               // (hang guard, as in svr_walk.hpp: unreachable for sane scenes)
-        // ---- DDA: on to this walk's next tentative collision (all lanes of the wave, each through its own cells) ----
-        bool found = false;
+        // DDA: on to this walk's next tentative collision (all lanes of the wave, each through its own cells) ...
+        int r;
         #pragma nounroll
-        for (;;) {
-            const uint32_t cl = (L.cls[(uint32_t)q >> 3] >> (((uint32_t)q & 7u) << 2)) & 15u;
-            const float te = fmin_(fmin_(tx, ty), fmin_(tz, tMax));
-            if (COUNT) c.ipre++;
-            if (cl != 0u) {
-                class_bound(cl, b, rb);
-                const float room = (te - t) * b;
-                if (S <= room) { t = fma_(S, rb, t); found = true; break; }
-                S -= room;
-            }
-            if (te >= tMax) break;                                        // the walk leaves the box
-            t = te;
-            if (tx <= ty && tx <= tz) { ix += sx; q += sx; tx += dtx; if ((uint32_t)ix >= (uint32_t)hgx) break; }
-            else if (ty <= tz) { iy += sy; q += qsy; ty += dty; if ((uint32_t)iy >= (uint32_t)hgy) break; }
-            else { iz += sz; q += qsz; tz += dtz; if ((uint32_t)iz >= (uint32_t)hgz) break; }
-        }
-        if (!found) return -SVR_FLT_MAX;
-        // ---- tentative collision (the lanes that found one, together): full-resolution `empty` bit, else fetch + accept test ----
-        if (COUNT) c.iters++;
-        const Cell cell = cell_of(s, orig + dir * t);
-        bool fetch = true;
-        if (s.has_empty) fetch = !cell_is_empty<false>(L, s, cell);
-        if (fetch) {
-            if (COUNT) { c.exec++; c.taps++; }
-            val = tex_fetch<LAYOUT>(s, cell) * s.densityScale;
-            const float ratio = alpha_of(L, s, val) * s.invSigmaMax;      // the reference's acceptance probability (woodcock_tracking.h:43) ...
-            if (rng_uniform(rng) * b < ratio) return t;                  // ... over the local majorant's share b of sigma_max
-        }
-        S = -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
+        do r = lm_step<COUNT>(s, L, g, w, c); while (r == 0);
+        if (r == 2) return -SVR_FLT_MAX;
+        // ... then the lanes that found one fetch together
+        if (lm_tentative<LAYOUT, COUNT>(s, L, g, w, orig, dir, rng, val, c)) return w.t;
     }
     return -SVR_FLT_MAX;
 }
+
+#ifndef SVR_LM_WAVES_PER_EU
+#define SVR_LM_WAVES_PER_EU 4
+#endif
+constexpr uint32_t LM_THREADS = 1024;
+static_assert(TILE_WAVES == LM_THREADS / 64, "the pending-radiance rows (svr_kernels.hpp) are sized for 16 waves per block");
 
 // one path: kernel_pathtracer's body (pathtracer.cu:205-277) with walk_lm as its sample_distance
 template <int LAYOUT, bool COUNT, bool DEPTH1, typename LDS>
@@ -124,13 +239,15 @@ SVR_DEV v3 trace_path_lm(const DevScene& s, const LDS& L_, uint32_t x, uint32_t 
             GroupMap map;
             map.g = gslot + ((threadIdx.x & 63u) & ((1u << P2) - 1u) & (GROUP_MAPS_PER_WAVE - 1u));
             const int r = walk_setup_group<true, true>(s, L_, P2, orig, dir, false, tMin, tMax, t_occ, map);
-            if (r > 0 && t_occ != INF) t = walk_lm<LAYOUT, COUNT>(s, L_, orig, dir, rng, t_occ, tMax, val, c);
+            if (r > 0 && t_occ != INF) t = walk_lm<LAYOUT, COUNT>(s, L_, orig, dir, rng, fmax_(t_occ, tMin), tMax, val, c);      // (the shared test starts at the group's earliest box entry)
         } else {
             float tNear, tFar;
             if (volume_intersect(s, orig, dir, tNear, tFar)) {                // woodcock_tracking.h:22-27
                 tMin = tNear < 0.f ? (float)1e-6 : tNear;
                 tMax = tFar;
-                t = walk_lm<LAYOUT, COUNT>(s, L_, orig, dir, rng, tMin, tMax, val, c);
+                // primary rays start at the first possibly-occupied parameter (per-lane whole-ray test), like those of a full wave
+                const float t0 = k == 0 ? first_occupied(s, L_, orig, dir, tMin, tMax) : tMin;
+                if (t0 != INF) t = walk_lm<LAYOUT, COUNT>(s, L_, orig, dir, rng, t0, tMax, val, c);
             }
         }
         if (k == 0 && ls_id >= 0) {                                           // pathtracer.cu:220-229
@@ -180,11 +297,307 @@ SVR_DEV v3 trace_path_lm(const DevScene& s, const LDS& L_, uint32_t x, uint32_t 
     return L;
 }
 
-#ifndef SVR_LM_WAVES_PER_EU
-#define SVR_LM_WAVES_PER_EU 4
+
+// ------------------------------------------------------------------------------------------------------------------
+// The POOL form of the same algorithm (traceDepth 1, folding launches): a wave-sized wavefront path tracer.
+//
+// Why.  In the straight-line form a wave's 64 paths advance in lockstep: a walk round (DDA to the next tentative collision,
+// one fetch) is paid by the whole wave until its slowest lane is through, and the counts are geometric -- PMC: as many
+// vector instructions as the global-majorant kernel at 35 % (c3) and 21 % (c3n) lane utilisation.  So a wave takes a
+// BATCH of LM_BATCH tasks (<= 1024 paths) through four stages, each of which keeps its lanes busy:
+//   gen     per task, in lockstep (the lanes are frames of the same pixels): generator, camera ray, light hit test, box,
+//           shared whole-ray test.  Rays with nothing occupied ahead end here (light / environment); the others become
+//           RAY RECORDS in the wave's queue memory;
+//   walk    a pool: every lane pops a ray record, walks it (walk state in registers), settles it, pops the next.  A
+//           collision becomes a HIT RECORD, a miss ends the path;
+//   shade   64 hit records at a time: VolumeSample, gradient, light sampling (pathtracer.cu:237-257) -- each a shadow RAY RECORD;
+//   walk    the pool again, over the shadow rays: transmittance x prepared estimate -> the path's radiance;
+//   fold    the batch's tasks into the accumulator (svr_tile_tasks.hpp).
+// Records live in the wave's slice of DevWork.queue (written and read back once by the same wave: L2 / Infinity Cache).
+// The radiance of a path goes to its task's row by id = (task-in-batch << 6 | lane), like the QUEUE builds of
+// svr_trace_tile.hip.  Every path executes the operations of trace_path_lm in the same order on its own generator, so the
+// pool is scheduling only: bit-identical to the straight-line form (tests/test_local_majorant_gpu.py).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t LM_BATCH = 16;                         // tasks per batch: <= LM_CAP ray records
+constexpr uint32_t LM_CAP = LM_BATCH * 64;
+constexpr uint32_t LM_RAY_WORDS = 17;                     // o(3) d(3) rng(6) meta p0..p3
+constexpr uint32_t LM_HIT_WORDS = 14;                     // pt(3) wo(3) val rng(6) meta
+#ifndef SVR_LM_STEPS_PER_TURN
+#define SVR_LM_STEPS_PER_TURN 6
 #endif
-constexpr uint32_t LM_THREADS = 1024;
-static_assert(TILE_WAVES == LM_THREADS / 64, "the pending-radiance rows (svr_kernels.hpp) are sized for 16 waves per block");
+constexpr uint32_t LM_STEPS_PER_TURN = SVR_LM_STEPS_PER_TURN;   // cells a walking lane may cross before the wave serves the tentative collisions
+static_assert((LM_RAY_WORDS + LM_HIT_WORDS) * LM_CAP <= REC_WORDS * QUEUE_CAP, "the pool's records fit the wave's queue slice");
+static_assert(LM_BATCH <= QUEUE_TASKS, "pending-radiance rows");
+// meta: id (10 bits: task-in-batch << 6 | lane) | light or (nearest light + 1) << 12
+SVR_DEV uint32_t lm_meta(uint32_t id, uint32_t light) { return id | (light << 12); }
+
+template <int LAYOUT, bool COUNT, typename LDS>
+SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, uint32_t n, const bool shadows, uint32_t* H, uint32_t& nH,
+                          float* pendL, Cnt& c)
+{
+    enum : uint32_t { IDLE = 0u, WALK = 1u, TENT = 2u, END = 3u };
+    const LmGrid g = lm_grid(s);
+    uint32_t st = IDLE, next = 0u;
+    // walk state
+    Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
+    v3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f);
+    LmWalk wk;
+    wk.t = wk.tMax = wk.S = wk.tx = wk.ty = wk.tz = wk.Ax = wk.Ay = wk.Az = 0.f; wk.rx = wk.ry = wk.rz = wk.b = wk.rb = 1.f;
+    wk.ix = wk.iy = wk.iz = wk.q = 0;
+    float tMin = 0.f, val = 0.f;
+    bool hit = false;
+    uint32_t meta = 0u;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    auto put = [&](v3 L) {
+        const uint32_t id = meta & 0x3ffu;
+        float* p = pendL + (id >> 6) * (3u * 64u) + (id & 63u);
+        p[0] = L.x; p[64] = L.y; p[128] = L.z;
+        st = IDLE;
+    };
+
+    for (uint32_t turn = 0; turn < (SVR_WALK_GUARD << 4); ++turn) {           // (hang guard: unreachable for sane scenes)
+        // ---- refill: idle lanes pop the next ray records ----
+        {
+            const uint64_t idle = __ballot(st == IDLE);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (next < n && (n_idle >= 16u || n_idle == 64u || __ballot(st != IDLE) == 0ull)) {
+                const uint32_t i = next + lane_rank(idle);
+                if (st == IDLE && i < n) {
+                    const uint32_t* r = R + i;
+                    o = rec_v3_load(r, LM_CAP); d = rec_v3_load(r + 3 * LM_CAP, LM_CAP);
+                    rec_rng_load(r + 6 * LM_CAP, LM_CAP, rng);
+                    meta = r[12 * LM_CAP];
+                    p0 = u2f(r[13 * LM_CAP]); p1 = u2f(r[14 * LM_CAP]); p2 = u2f(r[15 * LM_CAP]); p3 = u2f(r[16 * LM_CAP]);
+                    if (shadows) {
+                        // transmittance (transmittance.h:10-17): to the box exit along the light direction
+                        float sNear, sFar;
+                        hit = false;
+                        tMin = (float)1e-6; wk.tMax = SVR_FLT_MAX;
+                        if (volume_intersect(s, o, d, sNear, sFar)) {
+                            tMin = sNear < 0.f ? (float)1e-6 : sNear;
+                            lm_begin(s, g, wk, o, d, tMin, sFar, rng);
+                            st = WALK;
+                        } else st = END;
+                    } else {
+                        // primary: the gen stage has intersected the box and found the first possibly-occupied parameter
+                        hit = false;
+                        lm_begin(s, g, wk, o, d, p1, p2, rng);
+                        st = WALK;
+                    }
+                }
+                next = min(n, next + n_idle);
+            }
+        }
+        if (__ballot(st != IDLE) == 0ull) break;                          // no record left, no walk in flight
+        // ---- DDA: the walking lanes go on towards their next tentative collision (a few cells per turn) ----
+        #pragma nounroll
+        for (uint32_t k = 0; k < LM_STEPS_PER_TURN && __ballot(st == WALK) != 0ull; ++k)
+            if (st == WALK) {
+                const int r = lm_step<COUNT>(s, L_, g, wk, c);
+                st = r == 0 ? WALK : (r == 1 ? TENT : END);
+            }
+        // ---- tentative collisions: fetch + accept test ----
+        if (__ballot(st == TENT) != 0ull) {
+            if (st == TENT) {
+                hit = lm_tentative<LAYOUT, COUNT>(s, L_, g, wk, o, d, rng, val, c);
+                st = hit ? END : WALK;
+            }
+        }
+        // ---- settle the walks that are over (when they are many, or nothing else is left to do) ----
+        {
+            const uint64_t ended = __ballot(st == END);
+            if (ended != 0ull && ((uint32_t)__popcll(ended) >= 16u || __ballot(st == WALK || st == TENT) == 0ull)) {
+                if (shadows) {
+                    if (st == END) {
+                        // estimate_direct_light's tail (pathtracer.cu:191-198): p0..p2 = bsdf, p3 = pdf
+                        const float ts = hit ? wk.t : -SVR_FLT_MAX;
+                        const float Tr = ((ts > tMin) && (ts < wk.tMax)) ? 0.f : 1.f;
+                        const float kf = Tr * (float)s.num_lights;
+                        const DevLight& l = s.lights[(meta >> 12) & 15u];
+                        put(((V3(p0, p1, p2) * kf) * V3(l.radiance[0], l.radiance[1], l.radiance[2])) / p3);
+                    }
+                } else {
+                    // pathtracer.cu:220-235: the nearest light in front of the collision, else environment, else a scatter event
+                    const uint32_t ls = (meta >> 12) & 15u;                    // nearest light + 1, 0 = none
+                    bool to_hit = false;
+                    if (st == END) {
+                        const float tt = hit ? wk.t : SVR_FLT_MAX;
+                        if (ls != 0u && p0 < tt) {
+                            const DevLight& l = s.lights[ls - 1u];
+                            const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -d);
+                            put(V3(l.radiance[0], l.radiance[1], l.radiance[2]) * (cosTerm <= 0.f ? 0.f : 1.f));
+                        } else if (!hit) {
+                            put(s.env_on_escape ? env_radiance(s, d) : V3(0.f, 0.f, 0.f));
+                        } else to_hit = true;
+                    }
+                    const uint64_t mh = __ballot(to_hit);
+                    if (to_hit) {
+                        uint32_t* h = H + nH + lane_rank(mh);
+                        rec_v3_store(h, LM_CAP, o + d * wk.t); rec_v3_store(h + 3 * LM_CAP, LM_CAP, -d);
+                        h[6 * LM_CAP] = f2u(val);
+                        rec_rng_store(h + 7 * LM_CAP, LM_CAP, rng);
+                        h[13 * LM_CAP] = meta & 0x3ffu;
+                        st = IDLE;
+                    }
+                    nH += (uint32_t)__popcll(mh);
+                }
+            }
+        }
+    }
+}
+
+template <int LAYOUT, bool COUNT>
+__global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_pool(const DevScene s, const DevWork w)
+{
+    __shared__ LdsTileCull lds;
+    __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
+    __shared__ uint32_t pend_task[TILE_WAVES][QUEUE_TASKS];
+    lds_tile_load(lds, s, true);
+
+    const float INF = u2f(SVR_INF_BITS);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const TaskShape ts = task_shape(w);
+    const uint32_t fl2 = ts.fl2, P2 = ts.P2, tw2 = ts.tw2, th2 = ts.th2, wv = ts.wv;
+    const uint32_t n_tasks = ts.tiles_x * ts.tiles_y * ts.fgroups;
+    const uint32_t shard0 = blockIdx.x % TICKET_SHARDS;
+    const size_t wslot = (size_t)(blockIdx.x * TILE_WAVES + wave);
+    float* const gpend = w.pend + wslot * (QUEUE_TASKS * 3u * 64u);
+    uint32_t* const R = w.queue + wslot * (REC_WORDS * QUEUE_CAP);       // ray records
+    uint32_t* const H = R + (size_t)LM_RAY_WORDS * LM_CAP;               // hit records
+    Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // records and radiance rows are read back by other lanes of this wave
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    uint32_t si = 0u;                                                     // ticket counters visited so far
+    for (;;) {
+        // ---- gen: up to LM_BATCH tasks ----
+        uint32_t nb = 0u, nR = 0u;
+        while (nb < LM_BATCH && si < TICKET_SHARDS) {
+            const uint32_t shard = (shard0 + si) % TICKET_SHARDS;
+            uint32_t* ticket = w.ticket + shard * TICKET_STRIDE;
+            // away from the home counter, look before taking (a plain load of a drained counter is free)
+            if (si != 0u && __atomic_load_n(ticket, __ATOMIC_RELAXED) * TICKET_SHARDS + shard >= n_tasks) { ++si; continue; }
+            uint32_t u = 0;
+            if (lane == 0) u = atomicAdd(ticket, 1u);
+            u = __builtin_amdgcn_readfirstlane(u);
+            const uint32_t k = u * TICKET_SHARDS + shard;
+            if (k >= n_tasks) { ++si; continue; }
+            uint32_t tx, ty, fg;
+            task_decode(ts, k, tx, ty, fg);
+            if (COUNT) c.loops += (lane == 0);
+            const uint32_t pl = lane & ((1u << P2) - 1u);
+            const uint32_t slot = (fg << fl2) + (lane >> P2);
+            const uint32_t px = (tx << tw2) + (pl & ((1u << tw2) - 1u));
+            const uint32_t r = (ty << th2) + (pl >> tw2);
+            const bool live = px < wv && r < w.n_rows && slot < w.nframes;
+            const bool group_march = fl2 >= 3u && __ballot(live) == ~0ull;
+            // kernel_pathtracer up to the primary walk (pathtracer.cu:205-218), as in trace_path_lm
+            bool queued = false;
+            v3 L = V3(0.f, 0.f, 0.f), orig = L, dir = V3(0.f, 0.f, 1.f);
+            Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
+            float ls_t = 0.f, t0 = 0.f, tMax = 0.f;
+            int ls_id = -1;
+            if (live) {
+                const uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
+                rng_init(rng, wang_hash(w.frame0 + slot) + (y * s.imageW + x));
+                if (COUNT) c.paths++;
+                camera_ray(s, x, y, rng, orig, dir);
+                ls_id = nearest_light(s, orig, dir, ls_t);
+                float tMin = (float)1e-6;
+                tMax = SVR_FLT_MAX;
+                bool run = false;
+                if (group_march) {
+                    float t_occ;
+                    GroupMap map;
+                    map.g = &gmaps[wave][0] + ((threadIdx.x & 63u) & ((1u << P2) - 1u) & (GROUP_MAPS_PER_WAVE - 1u));
+                    const int rr = walk_setup_group<true, true>(s, lds, P2, orig, dir, false, tMin, tMax, t_occ, map);
+                    run = rr > 0 && t_occ != INF;
+                    t0 = fmax_(t_occ, tMin);                                   // (the shared test starts at the group's earliest box entry)
+                } else {
+                    float tNear, tFar;
+                    if (volume_intersect(s, orig, dir, tNear, tFar)) {
+                        tMin = tNear < 0.f ? (float)1e-6 : tNear;
+                        tMax = tFar;
+                        // (per-lane whole-ray test: the same early end as under the shared one)
+                        t0 = first_occupied(s, lds, orig, dir, tMin, tMax);
+                        run = t0 != INF;
+                    }
+                }
+                if (run) queued = true;
+                else if (ls_id >= 0) {                                        // t = FLT_MAX > ls.t: the light is seen (pathtracer.cu:220-229)
+                    const DevLight& l = s.lights[ls_id];
+                    const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -dir);
+                    L = V3(l.radiance[0], l.radiance[1], l.radiance[2]) * (cosTerm <= 0.f ? 0.f : 1.f);
+                } else if (s.env_on_escape) L = env_radiance(s, dir);
+            }
+            {
+                float* p = gpend + (size_t)nb * (3u * 64u) + lane;           // (queued paths overwrite theirs when they end)
+                p[0] = L.x; p[64] = L.y; p[128] = L.z;
+            }
+            const uint64_t mq = __ballot(queued);
+            if (queued) {
+                uint32_t* rr = R + nR + lane_rank(mq);
+                rec_v3_store(rr, LM_CAP, orig); rec_v3_store(rr + 3 * LM_CAP, LM_CAP, dir);
+                rec_rng_store(rr + 6 * LM_CAP, LM_CAP, rng);
+                rr[12 * LM_CAP] = lm_meta((nb << 6) | lane, (uint32_t)(ls_id + 1));
+                rr[13 * LM_CAP] = f2u(ls_t); rr[14 * LM_CAP] = f2u(t0); rr[15 * LM_CAP] = f2u(tMax); rr[16 * LM_CAP] = 0u;
+            }
+            nR += (uint32_t)__popcll(mq);
+            if (lane == 0) pend_task[wave][nb] = k;
+            ++nb;
+        }
+        if (nb == 0u) break;
+        // ---- walk: primary rays ----
+        uint32_t nH = 0u;
+        fence();
+        lm_walk_pool<LAYOUT, COUNT>(s, lds, R, nR, false, H, nH, gpend, c);
+        fence();
+        // ---- shade the collisions, 64 at a time: each becomes a shadow ray (or ends with L = 0) ----
+        uint32_t nS = 0u;
+        for (uint32_t i0 = 0u; i0 < nH; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            bool have = false;
+            Shade vs;
+            vs.pt = V3(0.f, 0.f, 0.f); vs.wo = vs.pt; vs.gradient = vs.pt; vs.color[0] = vs.color[1] = vs.color[2] = vs.color[3] = 0.f; vs.Pbrdf = 0.f; vs.st = 0;
+            Nee ne;
+            ne.wi = V3(0.f, 0.f, 1.f); ne.B = vs.pt; ne.pdf = 1.f; ne.light = 0u; ne.have = false;
+            Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
+            uint32_t id = 0u;
+            if (i < nH) {
+                const uint32_t* h = H + i;
+                vs.pt = rec_v3_load(h, LM_CAP); vs.wo = rec_v3_load(h + 3 * LM_CAP, LM_CAP);
+                const float val = u2f(h[6 * LM_CAP]);
+                rec_rng_load(h + 7 * LM_CAP, LM_CAP, rng);
+                id = h[13 * LM_CAP];
+                shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
+                have = ne.have;
+                if (!have) {                                                  // no light sample reaches the event: L = 0
+                    float* p = gpend + (id >> 6) * (3u * 64u) + (id & 63u);
+                    p[0] = 0.f; p[64] = 0.f; p[128] = 0.f;
+                }
+            }
+            const uint64_t ms = __ballot(have);
+            if (have) {
+                uint32_t* rr = R + nS + lane_rank(ms);                        // (the primary ray records have all been consumed)
+                rec_v3_store(rr, LM_CAP, vs.pt); rec_v3_store(rr + 3 * LM_CAP, LM_CAP, ne.wi);
+                rec_rng_store(rr + 6 * LM_CAP, LM_CAP, rng);
+                rr[12 * LM_CAP] = lm_meta(id, ne.light);
+                rr[13 * LM_CAP] = f2u(ne.B.x); rr[14 * LM_CAP] = f2u(ne.B.y); rr[15 * LM_CAP] = f2u(ne.B.z); rr[16 * LM_CAP] = f2u(ne.pdf);
+            }
+            nS += (uint32_t)__popcll(ms);
+        }
+        // ---- walk: shadow rays ----
+        fence();
+        uint32_t none = 0u;
+        lm_walk_pool<LAYOUT, COUNT>(s, lds, R, nS, true, H, none, gpend, c);
+        fence();
+        // ---- fold the batch ----
+        fold_pending(s, w, gpend, 64u, &pend_task[wave][0], nb);
+        fence();
+    }
+    if (COUNT) cnt_flush(w, c);
+}
 
 // Persistent 1024-thread blocks, one task = (64 >> f) pixels x (1 << f) frames per wave from 8 sharded tickets, centre-out
 // order, the frames of a launch folded into the accumulator in the kernel (svr_tile_tasks.hpp) -- the work distribution of
@@ -285,7 +698,9 @@ static hipError_t launch_lm_t(const DevScene& s, const DevWork& w, const LaunchC
     w2.frames_log2 = fl2;
     hipError_t e = hipMemsetAsync(w.ticket, 0, sizeof(uint32_t) * TICKET_SHARDS * TICKET_STRIDE, st);
     if (e != hipSuccess) return e;
-    if (w.traceDepth == 1u) hipLaunchKernelGGL((k_trace_lm<LAYOUT, COUNT, true>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
+    // traceDepth 1 (the reference's default), folding launch, queue memory at hand: the pool form
+    if (w.traceDepth == 1u && w.fold && w.queue != nullptr && !cfg.lm_straight) hipLaunchKernelGGL((k_trace_lm_pool<LAYOUT, COUNT>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
+    else if (w.traceDepth == 1u) hipLaunchKernelGGL((k_trace_lm<LAYOUT, COUNT, true>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
     else hipLaunchKernelGGL((k_trace_lm<LAYOUT, COUNT, false>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
     return hipGetLastError();
 }
@@ -295,6 +710,7 @@ static hipError_t launch_lm_t(const DevScene& s, const DevWork& w, const LaunchC
 hipError_t launch_trace_lm(const DevScene& s, const DevWork& w, const LaunchCfg& cfg, hipStream_t st)
 {
     if (s.empty_mask == nullptr || !s.ray_skip) return hipErrorInvalidValue;
+    if (s.layout == LAYOUT_CELL) return cfg.count ? launch_lm_t<LAYOUT_CELL, true>(s, w, cfg, st) : launch_lm_t<LAYOUT_CELL, false>(s, w, cfg, st);
     if (s.layout == LAYOUT_PAIR) return cfg.count ? launch_lm_t<LAYOUT_PAIR, true>(s, w, cfg, st) : launch_lm_t<LAYOUT_PAIR, false>(s, w, cfg, st);
     if (s.layout == LAYOUT_BRICK) return cfg.count ? launch_lm_t<LAYOUT_BRICK, true>(s, w, cfg, st) : launch_lm_t<LAYOUT_BRICK, false>(s, w, cfg, st);
     return cfg.count ? launch_lm_t<LAYOUT_LINEAR, true>(s, w, cfg, st) : launch_lm_t<LAYOUT_LINEAR, false>(s, w, cfg, st);

@@ -476,6 +476,8 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
 
 hipError_t launch_trace_tile(const DevScene& s, const DevWork& w, const LaunchCfg& cfg, hipStream_t st)
 {
+    if (s.layout == LAYOUT_CELL)
+        return cfg.count ? launch_tile_t<LAYOUT_CELL, true>(s, w, cfg, st) : launch_tile_t<LAYOUT_CELL, false>(s, w, cfg, st);
     if (s.layout == LAYOUT_PAIR)
         return cfg.count ? launch_tile_t<LAYOUT_PAIR, true>(s, w, cfg, st) : launch_tile_t<LAYOUT_PAIR, false>(s, w, cfg, st);
     if (s.layout == LAYOUT_LINEAR)

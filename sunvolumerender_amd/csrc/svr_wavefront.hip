@@ -380,6 +380,7 @@ hipError_t launch_wavefront(const DevScene& s, const DevWork& w, const LaunchCfg
 #define SVR_WF_DISPATCH(LAY)                                                                       \
     if (cfg.count) return skip ? launch_wf_t<LAY, true, true>(s, w, cfg, q, st) : launch_wf_t<LAY, true, false>(s, w, cfg, q, st); \
     return skip ? launch_wf_t<LAY, false, true>(s, w, cfg, q, st) : launch_wf_t<LAY, false, false>(s, w, cfg, q, st);
+    if (s.layout == LAYOUT_CELL) { SVR_WF_DISPATCH(LAYOUT_CELL) }
     if (s.layout == LAYOUT_PAIR) { SVR_WF_DISPATCH(LAYOUT_PAIR) }
     if (s.layout == LAYOUT_LINEAR) { SVR_WF_DISPATCH(LAYOUT_LINEAR) }
     SVR_WF_DISPATCH(LAYOUT_BRICK)

@@ -95,3 +95,21 @@ def test_cpp_host_headers_compile_and_link(tmp_path, example):
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert exe.exists()
+
+
+def test_cpp_rccl_assembly_example_compiles(tmp_path):
+    """examples/assemble_rccl.cpp -- a C++ host doing what bench.py --gpus N does (row shards, svr_assemble_frame with its own
+    ncclComm_t, tone map of the assembled frame) -- compiles and links against rccl.h / librccl.so and libsvr_hip.so.
+    (Running it needs >= 2 GPUs.)"""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists() or not Path("/opt/rocm/include/rccl/rccl.h").exists():
+        pytest.skip("no hipcc / rccl.h")
+    exe = tmp_path / "assemble_rccl"
+    cmd = [hipcc, "-std=c++14", "-O1", "-Wall", "-Werror", "-Wno-unused-result", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "assemble_rccl.cpp"),
+           "-o", str(exe), f"-L{abi.library_path().parent}", "-lsvr_hip", "-L/opt/rocm/lib", "-lrccl"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert exe.exists()

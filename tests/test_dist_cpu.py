@@ -77,3 +77,31 @@ def test_frame_assembler_single_process():
         assert dist.owned_row_count(H, 8, 0, world) == len(rows[0])
     a = dist.FrameAssembler(2048, 2048, 16, 1, 8)
     assert a.bytes_sent_per_rank() == 256 * 2048 * 12        # 6 MiB per peer, SURVEY.md 8(e)
+
+
+def test_native_strip_index_maths_matches_dist_py():
+    """svr_strip_rows_owned / svr_strip_row_to_y (plain host code of libsvr_hip.so: what svr_pack_strips, svr_unpack_strips and
+    svr_assemble_frame -- the C-ABI counterpart of dist.FrameAssembler for C++ hosts -- index with) against dist.owned_rows,
+    for frame heights that are and are not multiples of the strip, every rank of worlds 1..9; no GPU needed."""
+    import ctypes as C
+
+    sys.path.insert(0, str(ROOT))
+    from sunvolumerender_amd import abi, dist
+
+    lib = C.CDLL(str(abi.library_path()))
+    lib.svr_strip_rows_owned.restype = C.c_uint32
+    lib.svr_strip_rows_owned.argtypes = [C.c_uint32] * 4
+    lib.svr_strip_row_to_y.restype = C.c_uint32
+    lib.svr_strip_row_to_y.argtypes = [C.c_uint32] * 5
+    for H in (1, 7, 16, 80, 100, 1024, 1031):
+        for strip in (8, 16, 24):
+            for world in range(1, 10):
+                seen = np.zeros(H, dtype=np.int32)
+                for rank in range(world):
+                    rows = dist.owned_rows(H, strip, rank, world)
+                    assert lib.svr_strip_rows_owned(H, strip, rank, world) == len(rows), (H, strip, rank, world)
+                    ys = [lib.svr_strip_row_to_y(p, H, strip, rank, world) for p in range(len(rows))]
+                    assert ys == rows.tolist(), (H, strip, rank, world)
+                    assert lib.svr_strip_row_to_y(len(rows), H, strip, rank, world) == 0xFFFFFFFF
+                    seen[rows] += 1
+                assert (seen == 1).all()                      # the ranks' rows partition the frame

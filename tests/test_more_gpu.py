@@ -275,7 +275,7 @@ def _odd_scene(depth=2):
 def test_non_cubic_anisotropic_scene(hip_dev, kernel):
     sc = _odd_scene()
     ref_hdr, ref_img, ref_c = oracle_frames(sc, 3)
-    for layout in (abi.LAYOUT_BRICK, abi.LAYOUT_LINEAR):
+    for layout in (abi.LAYOUT_BRICK, abi.LAYOUT_LINEAR, abi.LAYOUT_CELL):
         hdr, img, c = hip_frames(hip_dev, sc, 3, kernel=kernel, layout=layout)
         assert_bit_exact(hdr, ref_hdr, f"odd scene kernel {kernel} layout {layout}")
         assert np.array_equal(img, ref_img)
@@ -355,6 +355,37 @@ def test_raycasting_lanes_per_ray(hip_dev, lanes_log2):
             canvas.close()
         assert np.array_equal(img, ref)
         assert cnt["raycast_steps"] == rc["raycast_steps"]
+
+
+@pytest.mark.parametrize("apeture", [0.0, 2.5])
+def test_lights_in_and_around_the_view_frustum(hip_dev, apeture):
+    """SVR_OPT_LIGHT_CULL drops lights no camera ray can reach from the primary rays' nearest-light test (a conservative
+    host-side frustum test, lens and pixel jitter included).  Lights squarely in view, straddling the frustum's edge and its
+    corner, just outside it, behind the camera and far off axis; pinhole and a wide thin lens: the oracle's image, bit for
+    bit, with the culling on and off -- and the lights in view really are seen."""
+    base = scenes.make_scene("tiny_head", trace_depth=2)
+    eye = host.zoom_to_extent_eye_dist(host.volume_size(base.dim, base.spacing), base.fov)
+    half_h = 0.45 * eye * np.tan(np.radians(base.fov) / 2)            # frustum half-height at depth 0.45 eye (the plane z = 0.55 eye, between camera and volume)
+    half_w = half_h * base.width / base.height
+    z = 0.55 * eye
+    toward_eye = (0.0, 0.0, 1.0)
+    lights = [host.make_area_light((0.3 * half_w, 0.2 * half_h, z), toward_eye, 2.0, (1.0, 0.8, 0.6), 40.0),          # in view
+              host.make_area_light((half_w, -0.5 * half_h, z), toward_eye, 3.0, (0.6, 1.0, 0.8), 40.0),               # straddles the edge
+              host.make_area_light((-half_w - 1.0, half_h + 1.0, z), toward_eye, 2.5, (0.7, 0.7, 1.0), 40.0),          # around the corner
+              host.make_area_light((half_w + 9.0, 0.0, z), toward_eye, 2.0, (1.0, 1.0, 1.0), 40.0),                   # just outside (a wide lens reaches it)
+              host.make_area_light((0.0, 0.0, eye + 6.0), (0.0, 0.0, -1.0), 5.0, (1.0, 1.0, 1.0), 40.0),              # behind the camera
+              scenes.default_light(base.dim, base.spacing)]                                                            # far off axis (the GUI default)
+    sc = dataclasses.replace(base, lights=lights, apeture=apeture, focal_length=1.0 if apeture == 0.0 else 0.8 * eye)
+    ref_hdr, ref_img, _ = oracle_frames(sc, 6)
+    for cull in (1, 0):
+        hip_dev.set_option(abi.OPT_LIGHT_CULL, cull)
+        for batch in (False, True):
+            hdr, img, _ = hip_frames(hip_dev, sc, 6, batch=batch)
+            assert_bit_exact(hdr, ref_hdr, f"lights around the frustum, apeture {apeture}, cull {cull}, batch {batch}")
+            assert np.array_equal(img, ref_img)
+    hip_dev.set_option(abi.OPT_LIGHT_CULL, 1)
+    # the light in view is seen directly (its radiance is far above anything the volume scatters)
+    assert ref_hdr.max() > 10.0 * np.median(ref_hdr[ref_hdr > 0])
 
 
 @pytest.mark.parametrize("case", ["tiny_head", "small_head", "odd_thin_lens", "c3_window"])

@@ -31,7 +31,7 @@ KERNELS = [
 
 
 @pytest.mark.parametrize("kernel,skip,kid", KERNELS, ids=[k[2] for k in KERNELS])
-@pytest.mark.parametrize("layout", [abi.LAYOUT_LINEAR, abi.LAYOUT_BRICK, abi.LAYOUT_PAIR], ids=["linear", "brick", "pair"])
+@pytest.mark.parametrize("layout", [abi.LAYOUT_LINEAR, abi.LAYOUT_BRICK, abi.LAYOUT_PAIR, abi.LAYOUT_CELL], ids=["linear", "brick", "pair", "cell"])
 @pytest.mark.parametrize("name,depth,frames", CASES)
 def test_pathtracer_bit_exact(hip_dev, name, depth, frames, kernel, skip, kid, layout):
     sc = scenes.make_scene(name, trace_depth=depth)
@@ -50,27 +50,29 @@ def test_pathtracer_bit_exact(hip_dev, name, depth, frames, kernel, skip, kid, l
         assert c["vol_taps_executed"] < c["vol_taps"] - ref_c["scatter_events"]
 
 
+@pytest.mark.parametrize("LAYOUT", [abi.LAYOUT_PAIR, abi.LAYOUT_CELL], ids=["pair", "cell"])
 @pytest.mark.parametrize("name,depth,frames", CASES + [("small_head", 2, 9)])
-def test_pair_layout_bit_exact(hip_dev, name, depth, frames):
-    """LAYOUT_PAIR (32-bit elements holding voxel x and x + 1: 4 gathers per fetch instead of 8) feeds the filter the same
-    eight voxels: tile kernel (per-frame calls and one folding launch, queue machine on and off) and ray caster."""
+def test_pair_layout_bit_exact(hip_dev, name, depth, frames, LAYOUT):
+    """LAYOUT_PAIR (32-bit elements holding voxel x and x + 1: 4 gathers per fetch instead of 8) and LAYOUT_CELL (16-byte
+    elements holding the 8 voxels of a trilinear cell: one load per fetch) feed the filter the same eight voxels: tile kernel
+    (per-frame calls and one folding launch, queue machine on and off) and ray caster."""
     sc = scenes.make_scene(name, trace_depth=depth)
     ref_hdr, ref_img, ref_c = oracle_frames(sc, frames)
-    hdr, img, c = hip_frames(hip_dev, sc, frames, kernel=abi.KERNEL_TILE, layout=abi.LAYOUT_PAIR)
-    assert_bit_exact(hdr, ref_hdr, f"{name} PAIR layout")
+    hdr, img, c = hip_frames(hip_dev, sc, frames, kernel=abi.KERNEL_TILE, layout=LAYOUT)
+    assert_bit_exact(hdr, ref_hdr, f"{name} layout {LAYOUT}")
     assert np.array_equal(img, ref_img)
     assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"]
     for q in (0, 2):
         hip_dev.set_option(abi.OPT_QUEUE, q)
-        b_hdr, _, _ = hip_frames(hip_dev, sc, frames, kernel=abi.KERNEL_TILE, layout=abi.LAYOUT_PAIR, batch=True)
+        b_hdr, _, _ = hip_frames(hip_dev, sc, frames, kernel=abi.KERNEL_TILE, layout=LAYOUT, batch=True)
         hip_dev.set_option(abi.OPT_QUEUE, 1)
-        assert_bit_exact(b_hdr, ref_hdr, f"{name} PAIR layout, one launch, queue={q}")
+        assert_bit_exact(b_hdr, ref_hdr, f"{name} layout {LAYOUT}, one launch, queue={q}")
     from oracle import binding
     from sunvolumerender_amd import host
     ref_rc, _ = binding.OracleScene(sc).render_raycasting()
     canvas = host.Canvas(hip_dev, sc.width, sc.height)
     try:
-        scenes.apply_to_canvas(sc, canvas, abi.LAYOUT_PAIR)
+        scenes.apply_to_canvas(sc, canvas, LAYOUT)
         canvas.SetRenderMode(host.Canvas.RENDER_MODE_RAYCASTING)
         canvas.paint(sync=True)
         assert np.array_equal(canvas.read_img(), ref_rc)
