@@ -252,6 +252,12 @@ int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_loc
 #define SVR_OPT_LIGHT_CULL 24       /* 1 (default): area lights that no camera ray can reach (behind the lens plane or outside the view frustum, lens
                                      * and pixel jitter included; conservative host-side test) are skipped by the primary rays' nearest-light test
                                      * (core/lights/light_sample.h:23-49).  Results unchanged */
+#define SVR_OPT_LM_TUNE 25          /* local-majorant pool kernel, speed only: macro-cells a walking lane may cross per turn | idle lanes that trigger a
+                                     * refill << 8 | ended walks that trigger their settling << 16 (each 1..64); 0 (default) = chosen per scene */
+#define SVR_OPT_LM_SUBCELLS 26      /* local-majorant mode: a walk spends its free path only in the occupied eighths (2 x 2 x 2 fine cells) of a macro-cell --
+                                     * fewer wasted tentative collisions where a surface cuts a cell.  0 off, 1 (default) where macro-cells are >= 16 voxels
+                                     * (volumes beyond 512^3), 2 always.  Changes the random numbers a path
+                                     * consumes (another, equally valid estimate), so it is part of the mode's definition, not a speed-only switch */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */

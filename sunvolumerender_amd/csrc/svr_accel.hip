@@ -153,6 +153,31 @@ hipError_t launch_fine_mask(const uint16_t* mm, uint32_t n_cells, const uint32_t
     return hipGetLastError();
 }
 
+// Occupancy of the 2 x 2 x 2 fine cells (half the edge) inside every macro-cell, one byte per macro-cell: bit dx + 2 dy + 4 dz is
+// set unless that fine cell is `empty` (fine level of k_empty_mask).  The local-majorant walk (svr_trace_lm.hip) spends its free
+// path only in the occupied eighths of a macro-cell.  A child beyond the fine grid's end repeats the last fine cell (the grids
+// clamp the same way).
+__global__ __launch_bounds__(256) void k_sub8(const uint32_t* __restrict__ fine_empty, int fgx, int fgy, int fgz, int gx, int gy, int gz, uint8_t* __restrict__ sub8)
+{
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= (uint32_t)gx * (uint32_t)gy * (uint32_t)gz) return;
+    const int mx = (int)(m % (uint32_t)gx), my = (int)((m / (uint32_t)gx) % (uint32_t)gy), mz = (int)(m / ((uint32_t)gx * (uint32_t)gy));
+    uint32_t bits = 0u;
+    for (int d = 0; d < 8; ++d) {
+        const int fx = min(2 * mx + (d & 1), fgx - 1), fy = min(2 * my + ((d >> 1) & 1), fgy - 1), fz = min(2 * mz + (d >> 2), fgz - 1);
+        const uint32_t f = (uint32_t)fx + (uint32_t)fgx * ((uint32_t)fy + (uint32_t)fgy * (uint32_t)fz);
+        if (!((fine_empty[f >> 5] >> (f & 31u)) & 1u)) bits |= 1u << d;
+    }
+    sub8[m] = (uint8_t)bits;
+}
+
+hipError_t launch_sub8(const uint32_t* fine_empty, int fgx, int fgy, int fgz, int gx, int gy, int gz, uint8_t* sub8, hipStream_t st)
+{
+    const uint32_t n = (uint32_t)gx * (uint32_t)gy * (uint32_t)gz;
+    hipLaunchKernelGGL(k_sub8, dim3((n + 255u) / 256u), dim3(256), 0, st, fine_empty, fgx, fgy, fgz, gx, gy, gz, sub8);
+    return hipGetLastError();
+}
+
 hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const float* tf_rgba, int tf_n, float densityScale,
                               float invSigmaMax, uint32_t* accel, hipStream_t st)
 {

@@ -121,11 +121,13 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
     size_t fine_mask_words = 0;
+    uint8_t* d_sub8 = nullptr;         // occupancy of the fine cells inside every macro-cell (local-majorant walks), MASK_WORDS_MAX * 32 bytes
+    bool sub8_valid = false;
     uint8_t* d_mask_tmp = nullptr;     // scratch of the distance transform
     bool mask_valid = false;
     uint64_t mask_vol = 0, mask_tf = 0, mask_tf_version = 0;
@@ -465,7 +467,10 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
                 g.fine_mask_words = fwords;
             }
             HIP_TRY(svr::launch_fine_mask(tv->mm_fine, (uint32_t)fcells, tt->zero_prefix, tt->nx, vol.densityScale, g.d_fine_mask, (uint32_t)fwords, g.stream));
+            if (!g.d_sub8) HIP_TRY(hipMalloc((void**)&g.d_sub8, (size_t)svr::MASK_WORDS_MAX * 32));
+            HIP_TRY(svr::launch_sub8(g.d_fine_mask, tv->fg_x, tv->fg_y, tv->fg_z, tv->mc_gx, tv->mc_gy, tv->mc_gz, g.d_sub8, g.stream));
         }
+        g.sub8_valid = tv->mm_fine != nullptr;
         HIP_TRY(svr::launch_bound_class(tv->mm, tv->mc_gx, tv->mc_gy, tv->mc_gz, (const float*)tt->data, tt->nx, vol.densityScale,
                                         s.invSigmaMax, g.d_mask, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
@@ -509,9 +514,15 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
     // would turn it on for cells >= 16 voxels)
     s.fine_mask = (tv->mm_fine && g.d_fine_mask && (g.opt_fine_mask == 2 || (g.opt_fine_mask == 1 && tv->mc_shift >= 4))) ? g.d_fine_mask : nullptr;
     s.fg_x = tv->fg_x; s.fg_y = tv->fg_y; s.fg_z = tv->fg_z; s.fg_xy = tv->fg_x * tv->fg_y;
+    // sub-cell occupancy pays where macro-cells are large (c5, 16 voxels: +6 %) and costs where they are small (c3, 8 voxels: -4 %)
+    s.sub8 = (g.sub8_valid && g.d_sub8 && (g.opt_lm_sub == 2 || (g.opt_lm_sub == 1 && tv->mc_shift >= 4))) ? g.d_sub8 : nullptr;
     s.has_empty = g.mask_has_empty ? 1u : 0u;
     s.bound_cull = (g.opt_bound_cull == 2 || (g.opt_bound_cull == 1 && g.mask_cull_useful)) ? 1u : 0u;
     s.park_end = (uint32_t)g.opt_park_end;
+    // pool tuning (same-box sweeps, gpurun_out/r03p_lm_tune.log): on the full-resolution grid (scenes with empty space) one cell per turn
+    // (c3 9 920 / c5 8 430 Msamples/s against 9 480 / 7 630 with three), on the half-resolution grid of fog-like media three cells
+    // and later refills (c3n 4 860 against 4 290 with one cell)
+    s.lm_tune = g.opt_lm_tune ? (uint32_t)g.opt_lm_tune : (g.mask_has_empty ? (1u | (16u << 8) | (16u << 16)) : (3u | (24u << 8) | (24u << 16)));
     return 0;
 }
 
@@ -843,6 +854,7 @@ void svr_shutdown(void)
     if (g.d_mask) hipFree(g.d_mask);
     if (g.d_mask_tmp) hipFree(g.d_mask_tmp);
     if (g.d_fine_mask) hipFree(g.d_fine_mask);
+    if (g.d_sub8) hipFree(g.d_sub8);
     if (g.d_counters) hipFree(g.d_counters);
     if (g.d_ticket) hipFree(g.d_ticket);
     if (g.d_queue) hipFree(g.d_queue);
@@ -882,19 +894,25 @@ void svr_clear_error(void) { g.err_code = 0; g.err_msg.clear(); }
 const char* svr_device_info(void) { ensure_init(); return g.info.c_str(); }
 
 // ---------------- textures ----------------
-static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz, int src_is_device, int layout, bool* oom);
+static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz, int src_is_device, int layout, int auto_rank, bool* oom);
 
 uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz, int src_is_device, int layout)
 {
-    // AUTO prefers PAIR (twice the memory of BRICK: 552 MB for 512^3); if the device has no room for it, BRICK is tried before giving up
-    bool oom = false;
-    uint64_t h = create_volume_texture(voxels, nx, ny, nz, src_is_device, layout, layout == SVR_LAYOUT_AUTO ? &oom : nullptr);
-    if (h == 0 && oom) h = create_volume_texture(voxels, nx, ny, nz, src_is_device, SVR_LAYOUT_BRICK, nullptr);
+    // AUTO prefers the layouts that trade memory for fewer gathers (CELL: 8 x the u16 volume, PAIR: 2 x); if the device has no
+    // room for one, the next smaller one is tried before giving up
+    if (layout != SVR_LAYOUT_AUTO) return create_volume_texture(voxels, nx, ny, nz, src_is_device, layout, 0, nullptr);
+    uint64_t h = 0;
+    for (int rank = 0; rank <= 2 && h == 0; ++rank) {
+        bool oom = false;
+        h = create_volume_texture(voxels, nx, ny, nz, src_is_device, SVR_LAYOUT_AUTO, rank, rank < 2 ? &oom : nullptr);
+        if (h == 0 && !oom) break;
+    }
     return h;
 }
 
 // oom != null: running out of device memory is reported through *oom instead of as an error (the caller retries with a smaller layout)
-static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz, int src_is_device, int layout, bool* oom)
+// auto_rank: under AUTO, 0 = best layout that fits the addressing limits, 1 = skip CELL, 2 = skip CELL and PAIR
+static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz, int src_is_device, int layout, int auto_rank, bool* oom)
 {
     if (ensure_init()) return 0;
     if (!voxels || nx <= 0 || ny <= 0 || nz <= 0) { fail(-6, "svr_create_volume_texture: bad arguments (%p, %d, %d, %d)", (const void*)voxels, nx, ny, nz); return 0; }
@@ -908,9 +926,11 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
         const size_t bz_ = ((size_t)nz + 2 * svr::VOL_PAD + svr::BRICK_Z - 1) / svr::BRICK_Z;
         const bool pair_ok = (bx * by * 512) < ((size_t)1 << 24) && bx * by * bz_ * 512 < ((size_t)1 << 32);
         // CELL: 16-byte elements -- the element index uses 24-bit multiplies by the brick-row / brick-slab strides, the byte offset 32 bits
-        const bool cell_ok = (bx * by * 128) < ((size_t)1 << 24) && bx * by * bz_ * 128 * 16 < ((size_t)1 << 32);
-        if (layout == SVR_LAYOUT_AUTO) layout = pair_ok ? SVR_LAYOUT_PAIR : (brick_ok ? SVR_LAYOUT_BRICK : SVR_LAYOUT_LINEAR);
-        if (layout == SVR_LAYOUT_CELL && !cell_ok) { fail(-6, "svr_create_volume_texture: %dx%dx%d is too large for the CELL layout (32-bit byte offsets of 16-byte elements); use PAIR or BRICK", nx, ny, nz); return 0; }
+        const bool cell_ok = (bx * by * 128) < ((size_t)1 << 24) && bx * by * bz_ * 128 < ((size_t)1 << 32);      // 32-bit element index, 64-bit byte offset
+        // AUTO: CELL (one 16-byte load per fetch; 8 x the memory of the u16 volume -- 2.2 GB for 512^3, 17 GB for 1024^3 of a 288 GB
+        // device), else PAIR, else BRICK; on hipErrorOutOfMemory the next smaller one is tried (svr_create_volume_texture)
+        if (layout == SVR_LAYOUT_AUTO) layout = auto_rank <= 0 && cell_ok ? SVR_LAYOUT_CELL : (auto_rank <= 1 && pair_ok ? SVR_LAYOUT_PAIR : (brick_ok ? SVR_LAYOUT_BRICK : SVR_LAYOUT_LINEAR));
+        if (layout == SVR_LAYOUT_CELL && !cell_ok) { fail(-6, "svr_create_volume_texture: %dx%dx%d is too large for the CELL layout; use PAIR or BRICK", nx, ny, nz); return 0; }
         if (layout == SVR_LAYOUT_PAIR && !pair_ok) { fail(-6, "svr_create_volume_texture: %dx%dx%d is too large for the PAIR layout (32-bit byte offsets); use BRICK", nx, ny, nz); return 0; }
         if (layout == SVR_LAYOUT_BRICK && !brick_ok) { fail(-6, "svr_create_volume_texture: %dx%d slices are too large for the BRICK layout; use LINEAR", nx, ny); return 0; }
     }
@@ -926,7 +946,7 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
         t->bnx = (int)bx; t->bny = (int)by; t->sy = 0; t->sz = 0;
         elems = bx * by * bz * (size_t)(svr::BRICK_X * svr::BRICK_Y * svr::BRICK_Z);
     }
-    if (elems >= ((size_t)1 << 31) || (layout == SVR_LAYOUT_CELL && elems >= ((size_t)1 << 28))) { delete t; fail(-6, "svr_create_volume_texture: %zu padded voxels exceed 32-bit byte offsets", elems); return 0; }
+    if (elems >= ((size_t)1 << 32) || (layout != SVR_LAYOUT_CELL && elems >= ((size_t)1 << 31))) { delete t; fail(-6, "svr_create_volume_texture: %zu padded voxels exceed 32-bit byte offsets", elems); return 0; }
     // macro-cell grid for empty-space skipping: smallest cell size whose bitmask fits MASK_WORDS_MAX words
     {
         int sh = 0;
@@ -960,7 +980,7 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
     if (staged) hipFree(staged);
     if (e != hipSuccess) {
-        const bool retry = oom != nullptr && e == hipErrorOutOfMemory && layout == SVR_LAYOUT_PAIR;
+        const bool retry = oom != nullptr && e == hipErrorOutOfMemory && (layout == SVR_LAYOUT_PAIR || layout == SVR_LAYOUT_CELL);
         if (t->data) hipFree(t->data);
         if (t->mm) hipFree(t->mm);
         if (t->mm_fine) hipFree(t->mm_fine);
@@ -1354,6 +1374,14 @@ int svr_set_option(int key, int value)
         g.opt_fine_mask = value; return 0;
     case SVR_OPT_FAST_MATH: g.opt_fast_math = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_LIGHT_CULL: g.opt_light_cull = value ? 1 : 0; return 0;
+    case SVR_OPT_LM_SUBCELLS:
+        if (value < 0 || value > 2) return fail(-6, "SVR_OPT_LM_SUBCELLS: bad value %d (0 off, 1 auto, 2 always)", value);
+        g.opt_lm_sub = value; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
+    case SVR_OPT_LM_TUNE: {
+        const int steps = value & 0xff, refill = (value >> 8) & 0xff, ended = (value >> 16) & 0xff;
+        if (value != 0 && (steps < 1 || steps > 64 || refill < 1 || refill > 64 || ended < 1 || ended > 64)) return fail(-6, "SVR_OPT_LM_TUNE: bad value 0x%x (cells per turn | idle lanes << 8 | ended walks << 16, each 1..64)", value);
+        g.opt_lm_tune = value; return 0;
+    }
     case SVR_OPT_LOCAL_MAJORANT:
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_LOCAL_MAJORANT: bad value %d (0 off, 1 on, 2 on with straight-line paths only)", value);
         g.opt_local_majorant = value; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
@@ -1402,6 +1430,8 @@ int svr_get_option(int key)
     case SVR_OPT_FAST_MATH: return g.opt_fast_math;
     case SVR_OPT_LOCAL_MAJORANT: return g.opt_local_majorant;
     case SVR_OPT_LIGHT_CULL: return g.opt_light_cull;
+    case SVR_OPT_LM_TUNE: return g.opt_lm_tune;
+    case SVR_OPT_LM_SUBCELLS: return g.opt_lm_sub;
     case SVR_OPT_QUEUE: return g.opt_queue;
     case SVR_OPT_PARK_END: return g.opt_park_end;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;

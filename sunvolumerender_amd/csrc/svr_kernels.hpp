@@ -72,6 +72,8 @@ hipError_t launch_empty_mask(const uint16_t* mm, int gx, int gy, int gz, const u
 // `empty` bits of a (fine) macro-cell level into plain global memory: mask[n_cells / 32]
 hipError_t launch_fine_mask(const uint16_t* mm, uint32_t n_cells, const uint32_t* tf_zero_prefix, int tf_n, float densityScale,
                             uint32_t* mask, uint32_t words, hipStream_t stream);
+// one byte per macro-cell: which of its 2 x 2 x 2 fine cells are NOT `empty` (fine_empty = the fine level's bits of launch_fine_mask)
+hipError_t launch_sub8(const uint32_t* fine_empty, int fgx, int fgy, int fgz, int gx, int gy, int gz, uint8_t* sub8, hipStream_t stream);
 // bound classes of the half-resolution macro-cells (4 bit each) + the BOUND_CLASSES thresholds, into accel + ACCEL_CLASS_OFF
 hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const float* tf_rgba, int tf_n, float densityScale,
                               float invSigmaMax, uint32_t* accel, hipStream_t stream);

@@ -48,9 +48,11 @@ struct DevScene {
     uint32_t ray_skip;             // 1: the clipped box lies inside the texture domain, so whole-ray tests are valid
     const uint32_t* fine_mask;     // `empty` bits of the fine level (cells of 2^(mc_shift-1)), global memory; null = not used
     int32_t fg_x, fg_y, fg_z, fg_xy;   // its grid and slice stride (cells)
+    const uint8_t* sub8;           // per macro-cell: occupancy bits of its 2 x 2 x 2 fine cells (svr_accel.hip, k_sub8); null = none (local-majorant walks)
     uint32_t has_empty;            // 0: not one macro-cell is `empty` (media without exactly transparent space): the walks skip the mask look-ups
     uint32_t bound_cull;           // 1: the bound-class table behind the masks is valid (majorant-bound fetch culling)
     uint32_t park_end;             // lane machine: lanes waiting for shading / a walk's end / a new record before the wave serves them
+    uint32_t lm_tune;              // local-majorant pool (svr_trace_lm.hip): cells per turn | idle lanes before a refill << 8 | ended walks before they are settled << 16
     float mc_scale[3];             // macro-grid coordinate = (p - vmin) * mc_scale + mc_off
     float mc_off;
     // ---- cudaTransferFunction ----

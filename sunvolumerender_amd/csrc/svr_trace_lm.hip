@@ -59,6 +59,7 @@ SVR_DEV LmGrid lm_grid(const DevScene& s)
 struct LmWalk {
     float t, tMax, S, tx, ty, tz, Ax, Ay, Az, rx, ry, rz, b, rb;
     int ix, iy, iz, q;
+    uint32_t run;              // consecutive empty cells crossed (a leap is tried from the third on)
 };
 
 // cell of the point at ray parameter t, and the (absolute) ray parameters of its far boundaries
@@ -97,6 +98,7 @@ SVR_DEV void lm_begin(const DevScene& s, const LmGrid& g, LmWalk& w, v3 o, v3 d,
     w.tz = Bz != 0.f ? ((float)(w.iz + (Bz > 0.f ? 1 : 0)) - w.Az) * w.rz : INF;
     w.q = w.ix + w.iy * g.sy + w.iz * g.sz;
     w.b = 1.f; w.rb = 1.f;
+    w.run = 0u;
     // free path at the global majorant (woodcock_tracking.h:34); a cell of bound b spends it at rate b
     w.S = -logf_unit(1.f - rng_uniform(rng)) * s.invSigmaMaxSI;
 }
@@ -113,12 +115,13 @@ SVR_DEV int lm_step(const DevScene& s, const LDS& L, const LmGrid& g, LmWalk& w,
         const bool empty = (L.emask[(uint32_t)w.q >> 5] >> ((uint32_t)w.q & 31u)) & 1u;
         const uint32_t hq = (uint32_t)((w.ix >> 1) + (w.iy >> 1) * s.mc_hgx + (w.iz >> 1) * s.mc_hgxy);
         cl = 0u;
-        if (!empty) cl = (L.cls[hq >> 3] >> ((hq & 7u) << 2)) & 15u;
-        else {
+        if (!empty) { cl = (L.cls[hq >> 3] >> ((hq & 7u) << 2)) & 15u; w.run = 0u; }
+        else if (++w.run >= 3u) {
             // Empty space: no free path is spent, so the walk may LEAP.  Every macro-cell within Chebyshev distance dd - 1 of this
             // one is empty (distance field, svr_accel.hip): the ray may advance until its largest-axis displacement is dd - 1
             // cells (first_occupied's sphere tracing, svr_walk.hpp) and pick up the DDA in the cell it lands in.  Boundaries are
-            // absolute, so where exactly a leap lands does not change what follows.
+            // absolute, so where exactly a leap lands does not change what follows.  (Tried from the third empty cell in a row on:
+            // the gaps between the cells of a surface are shorter than that.)
             const uint32_t dd = (L.dist[hq >> 3] >> ((hq & 7u) << 2)) & 15u;
             if (dd >= 4u) {
                 const float inv = fmin_(__builtin_fabsf(w.rx), fmin_(__builtin_fabsf(w.ry), __builtin_fabsf(w.rz))) * 0.999f;      // 1 / largest |B|
@@ -131,9 +134,36 @@ SVR_DEV int lm_step(const DevScene& s, const LDS& L, const LmGrid& g, LmWalk& w,
         cl = (L.cls[(uint32_t)w.q >> 3] >> (((uint32_t)w.q & 7u) << 2)) & 15u;
     if (cl != 0u) {
         class_bound(cl, w.b, w.rb);
-        const float room = (te - w.t) * w.b;                     // (<= 0 for the part of a cell behind the start of the walk)
-        if (w.S <= room) { w.t = fma_(w.S, w.rb, w.t); return 1; }
-        w.S -= fmax_(room, 0.f);
+        uint32_t sub = 0xffu;
+        if (g.fine && s.sub8 != nullptr) sub = s.sub8[w.q];
+        if (sub == 0xffu) {
+            const float room = (te - w.t) * w.b;                 // (<= 0 for the part of a cell behind the start of the walk)
+            if (w.S <= room) { w.t = fma_(w.S, w.rb, w.t); return 1; }
+            w.S -= fmax_(room, 0.f);
+        } else {
+            // A surface cuts this macro-cell: the free path is spent only in its occupied eighths (k_sub8).  The cell's three
+            // mid-planes cut the segment [t, te] into at most 4 pieces, each inside one fine cell (found from its midpoint).
+            const float INF = u2f(SVR_INF_BITS);
+            const float Bx = __builtin_amdgcn_rcpf(w.rx), By = __builtin_amdgcn_rcpf(w.ry), Bz = __builtin_amdgcn_rcpf(w.rz);     // (1 / inf = 0: an axis the ray does not move along)
+            const float hx = (float)w.ix + 0.5f, hy = (float)w.iy + 0.5f, hz = (float)w.iz + 0.5f;
+            const float mx = Bx != 0.f ? (hx - w.Ax) * w.rx : INF, my = By != 0.f ? (hy - w.Ay) * w.ry : INF, mz = Bz != 0.f ? (hz - w.Az) * w.rz : INF;
+            float ta = w.t;
+            #pragma nounroll
+            for (int k = 0; k < 4 && ta < te; ++k) {
+                float tb = te;
+                tb = mx > ta ? fmin_(tb, mx) : tb;
+                tb = my > ta ? fmin_(tb, my) : tb;
+                tb = mz > ta ? fmin_(tb, mz) : tb;
+                const float tm = 0.5f * (ta + tb);
+                const uint32_t child = (fma_(Bx, tm, w.Ax) >= hx ? 1u : 0u) | (fma_(By, tm, w.Ay) >= hy ? 2u : 0u) | (fma_(Bz, tm, w.Az) >= hz ? 4u : 0u);
+                if ((sub >> child) & 1u) {
+                    const float room = (tb - ta) * w.b;
+                    if (w.S <= room) { w.t = fma_(w.S, w.rb, ta); return 1; }
+                    w.S -= room;
+                }
+                ta = tb;
+            }
+        }
     }
     if (te >= w.tMax) return 2;
     w.t = fmax_(te, w.t);
@@ -192,7 +222,7 @@ SVR_DEV bool lm_tentative(const DevScene& s, const LDS& L, const LmGrid& g, LmWa
 // tMin, in the empty space in front of the first occupied cell) to tMax: the collision's t, or -FLT_MAX.  val = the
 // intensity fetched at the collision (pathtracer.cu:241).
 template <int LAYOUT, bool COUNT, typename LDS>
-SVR_DEV float walk_lm(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float t0, float tMax, float& val, Cnt& c)
+SVR_DEV float walk_lm(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng, float t0, float tMax, float& val, Cnt& c, bool dbg = false)
 {
     const LmGrid g = lm_grid(s);
     LmWalk w;
@@ -201,10 +231,19 @@ SVR_DEV float walk_lm(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng
         // DDA: on to this walk's next tentative collision (all lanes of the wave, each through its own cells) ...
         int r;
         #pragma nounroll
-        do r = lm_step<COUNT>(s, L, g, w, c); while (r == 0);
+        do {
+            r = lm_step<COUNT>(s, L, g, w, c);
+#ifdef SVR_LM_DEBUG
+            if (dbg) printf("  step r=%d t=%g S=%g cell=(%d,%d,%d) q=%d tx=%g ty=%g tz=%g tMax=%g b=%g\n", r, w.t, w.S, w.ix, w.iy, w.iz, w.q, w.tx, w.ty, w.tz, w.tMax, w.b);
+#endif
+        } while (r == 0);
         if (r == 2) return -SVR_FLT_MAX;
         // ... then the lanes that found one fetch together
-        if (lm_tentative<LAYOUT, COUNT>(s, L, g, w, orig, dir, rng, val, c)) return w.t;
+        const bool acc = lm_tentative<LAYOUT, COUNT>(s, L, g, w, orig, dir, rng, val, c);
+#ifdef SVR_LM_DEBUG
+        if (dbg) printf("  tentative t=%g val=%g accepted=%d newS=%g\n", w.t, val, (int)acc, w.S);
+#endif
+        if (acc) return w.t;
     }
     return -SVR_FLT_MAX;
 }
@@ -230,6 +269,12 @@ SVR_DEV v3 trace_path_lm(const DevScene& s, const LDS& L_, uint32_t x, uint32_t 
     camera_ray(s, x, y, rng, orig, dir);
     float ls_t;
     const int ls_id = nearest_light(s, orig, dir, ls_t);
+#ifdef SVR_LM_DEBUG
+    const bool dbg = x == SVR_LM_DEBUG_X && y == SVR_LM_DEBUG_Y && hashed == wang_hash(SVR_LM_DEBUG_F);
+    if (dbg) printf("path (%u,%u) orig=(%g,%g,%g) dir=(%g,%g,%g) ls_id=%d\n", x, y, orig.x, orig.y, orig.z, dir.x, dir.y, dir.z, ls_id);
+#else
+    const bool dbg = false;
+#endif
     for (uint32_t k = 0; k < traceDepth; ++k) {
         float tMin = (float)1e-6, tMax = SVR_FLT_MAX, val = 0.f, t = -SVR_FLT_MAX;
         if (k == 0 && group_march) {
@@ -247,7 +292,7 @@ SVR_DEV v3 trace_path_lm(const DevScene& s, const LDS& L_, uint32_t x, uint32_t 
                 tMax = tFar;
                 // primary rays start at the first possibly-occupied parameter (per-lane whole-ray test), like those of a full wave
                 const float t0 = k == 0 ? first_occupied(s, L_, orig, dir, tMin, tMax) : tMin;
-                if (t0 != INF) t = walk_lm<LAYOUT, COUNT>(s, L_, orig, dir, rng, t0, tMax, val, c);
+                if (t0 != INF) t = walk_lm<LAYOUT, COUNT>(s, L_, orig, dir, rng, t0, tMax, val, c, dbg);
             }
         }
         if (k == 0 && ls_id >= 0) {                                           // pathtracer.cu:220-229
@@ -268,6 +313,10 @@ SVR_DEV v3 trace_path_lm(const DevScene& s, const LDS& L_, uint32_t x, uint32_t 
         vs.pt = orig + dir * t;
         Nee ne;
         shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);                   // VolumeSample + light sampling, pathtracer.cu:237-257
+#ifdef SVR_LM_DEBUG
+        if (dbg) printf(" hit t=%g pt=(%g,%g,%g) val=%g color=(%g,%g,%g,%g) grad=(%g,%g,%g) Pbrdf=%g st=%d have=%d wi=(%g,%g,%g) B=(%g,%g,%g) pdf=%g light=%u\n", t, vs.pt.x, vs.pt.y, vs.pt.z, val,
+                        vs.color[0], vs.color[1], vs.color[2], vs.color[3], vs.gradient.x, vs.gradient.y, vs.gradient.z, vs.Pbrdf, vs.st, (int)ne.have, ne.wi.x, ne.wi.y, ne.wi.z, ne.B.x, ne.B.y, ne.B.z, ne.pdf, ne.light);
+#endif
         if (ne.have) {
             // transmittance (transmittance.h:10-17): a walk along the light direction to the box exit, 0 if it collides
             float sNear, sFar, sval = 0.f, ts = -SVR_FLT_MAX;
@@ -275,7 +324,7 @@ SVR_DEV v3 trace_path_lm(const DevScene& s, const LDS& L_, uint32_t x, uint32_t 
             if (volume_intersect(s, vs.pt, ne.wi, sNear, sFar)) {
                 sMin = sNear < 0.f ? (float)1e-6 : sNear;
                 sMax = sFar;
-                ts = walk_lm<LAYOUT, COUNT>(s, L_, vs.pt, ne.wi, rng, sMin, sMax, sval, c);
+                ts = walk_lm<LAYOUT, COUNT>(s, L_, vs.pt, ne.wi, rng, sMin, sMax, sval, c, dbg);
             }
             const float Tr = ((ts > sMin) && (ts < sMax)) ? 0.f : 1.f;
             const float kf = Tr * (float)s.num_lights;
@@ -322,10 +371,6 @@ constexpr uint32_t LM_BATCH = 16;                         // tasks per batch: <=
 constexpr uint32_t LM_CAP = LM_BATCH * 64;
 constexpr uint32_t LM_RAY_WORDS = 17;                     // o(3) d(3) rng(6) meta p0..p3
 constexpr uint32_t LM_HIT_WORDS = 14;                     // pt(3) wo(3) val rng(6) meta
-#ifndef SVR_LM_STEPS_PER_TURN
-#define SVR_LM_STEPS_PER_TURN 6
-#endif
-constexpr uint32_t LM_STEPS_PER_TURN = SVR_LM_STEPS_PER_TURN;   // cells a walking lane may cross before the wave serves the tentative collisions
 static_assert((LM_RAY_WORDS + LM_HIT_WORDS) * LM_CAP <= REC_WORDS * QUEUE_CAP, "the pool's records fit the wave's queue slice");
 static_assert(LM_BATCH <= QUEUE_TASKS, "pending-radiance rows");
 // meta: id (10 bits: task-in-batch << 6 | lane) | light or (nearest light + 1) << 12
@@ -337,13 +382,14 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
 {
     enum : uint32_t { IDLE = 0u, WALK = 1u, TENT = 2u, END = 3u };
     const LmGrid g = lm_grid(s);
+    const uint32_t steps_per_turn = s.lm_tune & 0xffu, refill_min = (s.lm_tune >> 8) & 0xffu, ended_min = (s.lm_tune >> 16) & 0xffu;
     uint32_t st = IDLE, next = 0u;
     // walk state
     Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
     v3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f);
     LmWalk wk;
     wk.t = wk.tMax = wk.S = wk.tx = wk.ty = wk.tz = wk.Ax = wk.Ay = wk.Az = 0.f; wk.rx = wk.ry = wk.rz = wk.b = wk.rb = 1.f;
-    wk.ix = wk.iy = wk.iz = wk.q = 0;
+    wk.ix = wk.iy = wk.iz = wk.q = 0; wk.run = 0u;
     float tMin = 0.f, val = 0.f;
     bool hit = false;
     uint32_t meta = 0u;
@@ -360,7 +406,7 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
         {
             const uint64_t idle = __ballot(st == IDLE);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (next < n && (n_idle >= 16u || n_idle == 64u || __ballot(st != IDLE) == 0ull)) {
+            if (next < n && (n_idle >= refill_min || __ballot(st == WALK || st == TENT) == 0ull)) {
                 const uint32_t i = next + lane_rank(idle);
                 if (st == IDLE && i < n) {
                     const uint32_t* r = R + i;
@@ -391,7 +437,7 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
         if (__ballot(st != IDLE) == 0ull) break;                          // no record left, no walk in flight
         // ---- DDA: the walking lanes go on towards their next tentative collision (a few cells per turn) ----
         #pragma nounroll
-        for (uint32_t k = 0; k < LM_STEPS_PER_TURN && __ballot(st == WALK) != 0ull; ++k)
+        for (uint32_t k = 0; k < steps_per_turn && __ballot(st == WALK) != 0ull; ++k)
             if (st == WALK) {
                 const int r = lm_step<COUNT>(s, L_, g, wk, c);
                 st = r == 0 ? WALK : (r == 1 ? TENT : END);
@@ -406,7 +452,7 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
         // ---- settle the walks that are over (when they are many, or nothing else is left to do) ----
         {
             const uint64_t ended = __ballot(st == END);
-            if (ended != 0ull && ((uint32_t)__popcll(ended) >= 16u || __ballot(st == WALK || st == TENT) == 0ull)) {
+            if (ended != 0ull && ((uint32_t)__popcll(ended) >= ended_min || __ballot(st == WALK || st == TENT) == 0ull)) {
                 if (shadows) {
                     if (st == END) {
                         // estimate_direct_light's tail (pathtracer.cu:191-198): p0..p2 = bsdf, p3 = pdf

@@ -98,11 +98,12 @@ SVR_DEV float tex_fetch(const DevScene& s, const Cell& c)
         // brick = 8x4x4 elements of 16 bytes = 2 KB; element (i, j, k) = the 8 voxels of the trilinear cell (i, j, k), as four
         // PAIR words (y, z), (y + 1, z), (y, z + 1), (y + 1, z + 1): a fetch is ONE 16-byte load from ONE 32-byte sector instead of
         // 4 gathers from 4 sectors -- a quarter of the gather instructions, tag look-ups and HBM sectors of PAIR -- for 8 x the
-        // memory of the u16 volume: 2.2 GB for 512^3 of a 288 GB device
+        // memory of the u16 volume: 2.2 GB for 512^3, 17 GB for 1024^3 of a 288 GB device
         const uint32_t X0 = ((i >> 3) << 7) + (i & 7u);
         const uint32_t Y0 = __umul24(j >> 2, (uint32_t)s.bnx << 7) + ((j & 3u) << 3);
         const uint32_t Z0 = __umul24(k >> 2, (uint32_t)(s.bny * s.bnx) << 7) + ((k & 3u) << 5);      // < 2^24, checked on the host
-        const uint4 c4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(vox) + ((X0 + Y0 + Z0) << 4));
+        // (64-bit byte offset: 1024^3 is 17 GB in this layout)
+        const uint4 c4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(vox) + ((uint64_t)(X0 + Y0 + Z0) << 4));
         v000 = (float)(c4.x & 0xffffu); v100 = (float)(c4.x >> 16);
         v010 = (float)(c4.y & 0xffffu); v110 = (float)(c4.y >> 16);
         v001 = (float)(c4.z & 0xffffu); v101 = (float)(c4.z >> 16);

@@ -31,6 +31,8 @@ for spec in sys.argv[1:]:
     A, A2 = render(0, N)
     B = 2 * A2 - A
     F, F2 = render(mode, N)
+    bad = ~(np.isfinite(A2).all(axis=2) & np.isfinite(A).all(axis=2) & np.isfinite(F2).all(axis=2))      # (the reference's own 0/0 pixels)
+    A, A2, B, F2 = (np.where(bad[..., None], 0.0, v) for v in (A, A2, B, F2))
     npx = A.shape[0] * A.shape[1]
     se = np.sqrt(2.0 * np.mean((A - B) ** 2, axis=(0, 1)) / 4.0 / npx)
     m = A2.mean(axis=(0, 1))
