@@ -641,6 +641,10 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     // OPT-IN local majorants (svr_trace_lm.hip): needs the class table and whole-ray validity; its folding launches keep the waves'
     // pending radiance in the rows next to the record queues
     const bool local_majorant = g.opt_local_majorant && cfg.kernel == svr::KERNEL_TILE && s.empty_mask != nullptr && s.ray_skip && !g.opt_debug_stop;
+    // the slot-per-path pool of deeper paths settles its walks (slot loads and stores) and refills less eagerly: 2 cells per turn, a
+    // refill from 32 idle lanes, settling from 48 ended walks (c3 depth 4: 3 390 Msamples/s against 2 630 with the depth-1 setting,
+    // c3n depth 4: 1 080 against 810; gpurun_out/r03u_tune.log)
+    if (local_majorant && !g.opt_lm_tune && rp->traceDepth > 1) s.lm_tune = 2u | (32u << 8) | (48u << 16);
     if (local_majorant) use_queue = false;
     if (use_queue || (local_majorant && fold_batch)) {
         bool available = true;

@@ -645,6 +645,352 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
     if (COUNT) cnt_flush(w, c);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The pool form for traceDepth > 1: ONE SLOT PER PATH.  A path of the batch owns slot id = (task-in-batch << 6 | lane) of the wave's
+// queue slice for its whole life; the slot holds everything that survives between the stages of a bounce (SoA, stride LM_CAP
+// words), and the stages hand each other LISTS of slot numbers (dense: ballot + mbcnt):
+//   gen -> W | per bounce k:  walk(W) -> H | shade(H) -> S (or A: no light sample) | walk(S) -> A | bsdf(A) -> W | ... | fold
+// Every stage runs full waves: the walks as a pool (lm_walk_pool_deep: a lane pops a slot, walks with its state in registers, settles
+// the result into the slot, pops the next), shading and BSDF sampling 64 slots at a time.  Each path executes trace_path_lm's
+// operations in trace_path_lm's order on its own generator (the shadow walk's draws come before sample_bsdf's, the generator
+// lives in the slot between stages), so this, too, is scheduling only: bit-identical to the straight-line form.
+// ------------------------------------------------------------------------------------------------------------------
+enum : uint32_t { SF_O = 0, SF_D = 3, SF_RNG = 6, SF_META = 12, SF_L = 13, SF_T = 16, SF_WO = 19, SF_GRAD = 22, SF_COLOR = 25, SF_PBRDF = 28, SF_B = 29,
+                  SF_PDF = 32, SF_VAL = 33, SF_LST = 34, SF_T0 = 35, SF_TMAX = 36, SF_WORDS = 37 };
+constexpr uint32_t LM_LISTS = 4;                                                  // W (walks), H (hits), S (shadow walks), A (BSDF sampling)
+static_assert((SF_WORDS + LM_LISTS) * LM_CAP <= REC_WORDS * QUEUE_CAP, "slots + lists fit the wave's queue slice");
+// meta: nearest light + 1 (bits 0-3, primary rays) | sampled light (bits 4-7) | shading type (bit 8)
+enum : uint32_t { LMK_PRIMARY = 0u, LMK_CONT = 1u, LMK_SHADOW = 2u };
+
+template <int LAYOUT, bool COUNT, typename LDS>
+SVR_DEV void lm_walk_pool_deep(const DevScene& s, const LDS& L_, uint32_t* F, const uint32_t* list, uint32_t n, const uint32_t kind, const bool last_bounce,
+                               uint32_t* out, uint32_t& n_out, float* pendL, Cnt& c)
+{
+    enum : uint32_t { IDLE = 0u, WALK = 1u, TENT = 2u, END = 3u };
+    const LmGrid g = lm_grid(s);
+    const uint32_t steps_per_turn = s.lm_tune & 0xffu, refill_min = (s.lm_tune >> 8) & 0xffu, ended_min = (s.lm_tune >> 16) & 0xffu;
+    uint32_t st = IDLE, next = 0u, slot = 0u;
+    Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
+    v3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f);
+    LmWalk wk;
+    wk.t = wk.tMax = wk.S = wk.tx = wk.ty = wk.tz = wk.Ax = wk.Ay = wk.Az = 0.f; wk.rx = wk.ry = wk.rz = wk.b = wk.rb = 1.f;
+    wk.ix = wk.iy = wk.iz = wk.q = 0; wk.run = 0u;
+    float tMin = 0.f, val = 0.f;
+    bool hit = false;
+    auto put = [&](v3 L) {
+        float* p = pendL + (slot >> 6) * (3u * 64u) + (slot & 63u);
+        p[0] = L.x; p[64] = L.y; p[128] = L.z;
+        st = IDLE;
+    };
+    for (uint32_t turn = 0; turn < (SVR_WALK_GUARD << 4); ++turn) {           // (hang guard: unreachable for sane scenes)
+        // ---- refill: idle lanes pop the next slots of the list ----
+        {
+            const uint64_t idle = __ballot(st == IDLE);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (next < n && (n_idle >= refill_min || __ballot(st == WALK || st == TENT) == 0ull)) {
+                const uint32_t i = next + lane_rank(idle);
+                if (st == IDLE && i < n) {
+                    slot = list[i];
+                    const uint32_t* f = F + slot;
+                    o = rec_v3_load(f + SF_O * LM_CAP, LM_CAP); d = rec_v3_load(f + SF_D * LM_CAP, LM_CAP);
+                    rec_rng_load(f + SF_RNG * LM_CAP, LM_CAP, rng);
+                    hit = false;
+                    if (kind == LMK_PRIMARY) {
+                        // the gen stage has intersected the box and found the first possibly-occupied parameter
+                        lm_begin(s, g, wk, o, d, u2f(f[SF_T0 * LM_CAP]), u2f(f[SF_TMAX * LM_CAP]), rng);
+                        st = WALK;
+                    } else {
+                        // sample_distance's box (woodcock_tracking.h:22-27) / transmittance's (transmittance.h:10-17): to the box exit
+                        float sNear, sFar;
+                        tMin = (float)1e-6; wk.tMax = SVR_FLT_MAX;
+                        if (volume_intersect(s, o, d, sNear, sFar)) {
+                            tMin = sNear < 0.f ? (float)1e-6 : sNear;
+                            lm_begin(s, g, wk, o, d, tMin, sFar, rng);
+                            st = WALK;
+                        } else st = END;
+                    }
+                }
+                next = min(n, next + n_idle);
+            }
+        }
+        if (__ballot(st != IDLE) == 0ull) break;
+        // ---- DDA, tentative collisions (as in lm_walk_pool) ----
+        #pragma nounroll
+        for (uint32_t k = 0; k < steps_per_turn && __ballot(st == WALK) != 0ull; ++k)
+            if (st == WALK) {
+                const int r = lm_step<COUNT>(s, L_, g, wk, c);
+                st = r == 0 ? WALK : (r == 1 ? TENT : END);
+            }
+        if (__ballot(st == TENT) != 0ull) {
+            if (st == TENT) {
+                hit = lm_tentative<LAYOUT, COUNT>(s, L_, g, wk, o, d, rng, val, c);
+                st = hit ? END : WALK;
+            }
+        }
+        // ---- settle the walks that are over ----
+        {
+            const uint64_t ended = __ballot(st == END);
+            if (ended != 0ull && ((uint32_t)__popcll(ended) >= ended_min || __ballot(st == WALK || st == TENT) == 0ull)) {
+                bool to_out = false;
+                if (st == END) {
+                    uint32_t* f = F + slot;
+                    if (kind == LMK_SHADOW) {
+                        // estimate_direct_light's tail (pathtracer.cu:191-198) and L = L + T * Ld (:257)
+                        const float ts = hit ? wk.t : -SVR_FLT_MAX;
+                        const float Tr = ((ts > tMin) && (ts < wk.tMax)) ? 0.f : 1.f;
+                        const float kf = Tr * (float)s.num_lights;
+                        const DevLight& l = s.lights[(f[SF_META * LM_CAP] >> 4) & 15u];
+                        const v3 B = rec_v3_load(f + SF_B * LM_CAP, LM_CAP), T = rec_v3_load(f + SF_T * LM_CAP, LM_CAP);
+                        const float pdf = u2f(f[SF_PDF * LM_CAP]);
+                        const v3 L = rec_v3_load(f + SF_L * LM_CAP, LM_CAP) + T * (((B * kf) * V3(l.radiance[0], l.radiance[1], l.radiance[2])) / pdf);
+                        if (last_bounce) put(L);
+                        else {
+                            rec_v3_store(f + SF_L * LM_CAP, LM_CAP, L);
+                            rec_rng_store(f + SF_RNG * LM_CAP, LM_CAP, rng);
+                            to_out = true;                                      // on to the BSDF sampling
+                        }
+                    } else {
+                        // pathtracer.cu:220-235: (k = 0) the nearest light in front of the collision; no collision: environment; else a scatter event
+                        const uint32_t ls = kind == LMK_PRIMARY ? (f[SF_META * LM_CAP] & 15u) : 0u;
+                        const float tt = hit ? wk.t : SVR_FLT_MAX;
+                        if (ls != 0u && u2f(f[SF_LST * LM_CAP]) < tt) {
+                            const DevLight& l = s.lights[ls - 1u];
+                            const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -d);
+                            put(V3(l.radiance[0], l.radiance[1], l.radiance[2]) * (cosTerm <= 0.f ? 0.f : 1.f));      // (L = 0, T = 1 at k = 0)
+                        } else if (!hit) {
+                            v3 L = rec_v3_load(f + SF_L * LM_CAP, LM_CAP);
+                            if (s.env_on_escape) L = L + rec_v3_load(f + SF_T * LM_CAP, LM_CAP) * env_radiance(s, d);
+                            put(L);
+                        } else {
+                            rec_v3_store(f + SF_O * LM_CAP, LM_CAP, o + d * wk.t); rec_v3_store(f + SF_WO * LM_CAP, LM_CAP, -d);
+                            f[SF_VAL * LM_CAP] = f2u(val);
+                            rec_rng_store(f + SF_RNG * LM_CAP, LM_CAP, rng);
+                            to_out = true;                                      // on to the shading
+                        }
+                    }
+                }
+                const uint64_t mo = __ballot(to_out);
+                if (to_out) { out[n_out + lane_rank(mo)] = slot; st = IDLE; }
+                n_out += (uint32_t)__popcll(mo);
+            }
+        }
+    }
+}
+
+// kernel_pathtracer up to the primary walk (pathtracer.cu:205-218), as in trace_path_lm: generator, camera ray, nearest light, box, whole-ray
+// test (shared by the pixel's frames when the wave is full).  run = the ray has something occupied ahead; otherwise L is final.
+struct LmGen { bool run; v3 L, orig, dir; Rng rng; float ls_t, t0, tMax; int ls_id; };
+template <bool COUNT, typename LDS>
+SVR_DEV LmGen lm_gen(const DevScene& s, const LDS& lds, GroupMapShared* gm, bool live, bool group_march, uint32_t P2, uint32_t x, uint32_t y, uint32_t hashed, Cnt& c)
+{
+    const float INF = u2f(SVR_INF_BITS);
+    LmGen g;
+    g.run = false; g.L = V3(0.f, 0.f, 0.f); g.orig = g.L; g.dir = V3(0.f, 0.f, 1.f);
+    g.rng = Rng{0u, 0u, 0u, 0u, 0u, 0u};
+    g.ls_t = 0.f; g.t0 = 0.f; g.tMax = 0.f; g.ls_id = -1;
+    if (live) {
+        rng_init(g.rng, hashed + (y * s.imageW + x));
+        if (COUNT) c.paths++;
+        camera_ray(s, x, y, g.rng, g.orig, g.dir);
+        g.ls_id = nearest_light(s, g.orig, g.dir, g.ls_t);
+        float tMin = (float)1e-6;
+        g.tMax = SVR_FLT_MAX;
+        if (group_march) {
+            float t_occ;
+            GroupMap map;
+            map.g = gm + ((threadIdx.x & 63u) & ((1u << P2) - 1u) & (GROUP_MAPS_PER_WAVE - 1u));
+            const int rr = walk_setup_group<true, true>(s, lds, P2, g.orig, g.dir, false, tMin, g.tMax, t_occ, map);
+            g.run = rr > 0 && t_occ != INF;
+            g.t0 = fmax_(t_occ, tMin);                                   // (the shared test starts at the group's earliest box entry)
+        } else {
+            float tNear, tFar;
+            if (volume_intersect(s, g.orig, g.dir, tNear, tFar)) {
+                tMin = tNear < 0.f ? (float)1e-6 : tNear;
+                g.tMax = tFar;
+                g.t0 = first_occupied(s, lds, g.orig, g.dir, tMin, g.tMax);      // (per-lane whole-ray test: the same early end as under the shared one)
+                g.run = g.t0 != INF;
+            }
+        }
+        if (!g.run) {
+            if (g.ls_id >= 0) {                                           // t = FLT_MAX > ls.t: the light is seen (pathtracer.cu:220-229)
+                const DevLight& l = s.lights[g.ls_id];
+                const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -g.dir);
+                g.L = V3(l.radiance[0], l.radiance[1], l.radiance[2]) * (cosTerm <= 0.f ? 0.f : 1.f);
+            } else if (s.env_on_escape) g.L = env_radiance(s, g.dir);
+        }
+    }
+    return g;
+}
+
+template <int LAYOUT, bool COUNT>
+__global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_pool_deep(const DevScene s, const DevWork w)
+{
+    __shared__ LdsTileCull lds;
+    __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
+    __shared__ uint32_t pend_task[TILE_WAVES][QUEUE_TASKS];
+    lds_tile_load(lds, s, true);
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const TaskShape ts = task_shape(w);
+    const uint32_t fl2 = ts.fl2, P2 = ts.P2, tw2 = ts.tw2, th2 = ts.th2, wv = ts.wv;
+    const uint32_t n_tasks = ts.tiles_x * ts.tiles_y * ts.fgroups;
+    const uint32_t shard0 = blockIdx.x % TICKET_SHARDS;
+    const uint32_t depth = w.traceDepth;
+    const size_t wslot = (size_t)(blockIdx.x * TILE_WAVES + wave);
+    float* const gpend = w.pend + wslot * (QUEUE_TASKS * 3u * 64u);
+    uint32_t* const F = w.queue + wslot * (REC_WORDS * QUEUE_CAP);         // slot fields
+    uint32_t* const LW = F + (size_t)SF_WORDS * LM_CAP;                    // lists
+    uint32_t* const LH = LW + LM_CAP;
+    uint32_t* const LS = LH + LM_CAP;
+    uint32_t* const LA = LS + LM_CAP;
+    Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // slots, lists and radiance rows are read back by other lanes of this wave
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    uint32_t si = 0u;
+    for (;;) {
+        // ---- gen: up to LM_BATCH tasks ----
+        uint32_t nb = 0u, nW = 0u;
+        while (nb < LM_BATCH && si < TICKET_SHARDS) {
+            const uint32_t shard = (shard0 + si) % TICKET_SHARDS;
+            uint32_t* ticket = w.ticket + shard * TICKET_STRIDE;
+            if (si != 0u && __atomic_load_n(ticket, __ATOMIC_RELAXED) * TICKET_SHARDS + shard >= n_tasks) { ++si; continue; }
+            uint32_t u = 0;
+            if (lane == 0) u = atomicAdd(ticket, 1u);
+            u = __builtin_amdgcn_readfirstlane(u);
+            const uint32_t k = u * TICKET_SHARDS + shard;
+            if (k >= n_tasks) { ++si; continue; }
+            uint32_t tx, ty, fg;
+            task_decode(ts, k, tx, ty, fg);
+            if (COUNT) c.loops += (lane == 0);
+            const uint32_t pl = lane & ((1u << P2) - 1u);
+            const uint32_t fslot = (fg << fl2) + (lane >> P2);
+            const uint32_t px = (tx << tw2) + (pl & ((1u << tw2) - 1u));
+            const uint32_t r = (ty << th2) + (pl >> tw2);
+            const bool live = px < wv && r < w.n_rows && fslot < w.nframes;
+            const bool group_march = fl2 >= 3u && __ballot(live) == ~0ull;
+            const LmGen g = lm_gen<COUNT>(s, lds, &gmaps[wave][0], live, group_march, P2, w.x0 + px, live ? owned_row_to_y(w, r) : 0u, wang_hash(w.frame0 + fslot), c);
+            {
+                float* p = gpend + (size_t)nb * (3u * 64u) + lane;       // (queued paths overwrite theirs when they end)
+                p[0] = g.L.x; p[64] = g.L.y; p[128] = g.L.z;
+            }
+            const uint32_t id = (nb << 6) | lane;
+            const uint64_t mq = __ballot(g.run);
+            if (g.run) {
+                uint32_t* f = F + id;
+                rec_v3_store(f + SF_O * LM_CAP, LM_CAP, g.orig); rec_v3_store(f + SF_D * LM_CAP, LM_CAP, g.dir);
+                rec_rng_store(f + SF_RNG * LM_CAP, LM_CAP, g.rng);
+                f[SF_META * LM_CAP] = (uint32_t)(g.ls_id + 1);
+                rec_v3_store(f + SF_L * LM_CAP, LM_CAP, V3(0.f, 0.f, 0.f)); rec_v3_store(f + SF_T * LM_CAP, LM_CAP, V3(1.f, 1.f, 1.f));
+                f[SF_LST * LM_CAP] = f2u(g.ls_t); f[SF_T0 * LM_CAP] = f2u(g.t0); f[SF_TMAX * LM_CAP] = f2u(g.tMax);
+                LW[nW + lane_rank(mq)] = id;
+            }
+            nW += (uint32_t)__popcll(mq);
+            if (lane == 0) pend_task[wave][nb] = k;
+            ++nb;
+        }
+        if (nb == 0u) break;
+        for (uint32_t k = 0; k < depth && nW != 0u; ++k) {
+            const bool last = k + 1u >= depth;
+            // ---- walk: this bounce's rays -> hits ----
+            uint32_t nH = 0u;
+            fence();
+            lm_walk_pool_deep<LAYOUT, COUNT>(s, lds, F, LW, nW, k == 0u ? LMK_PRIMARY : LMK_CONT, last, LH, nH, gpend, c);
+            fence();
+            // ---- shade the hits, 64 at a time (VolumeSample + light sampling, pathtracer.cu:237-257) ----
+            uint32_t nS = 0u, nA = 0u;
+            for (uint32_t i0 = 0u; i0 < nH; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                bool to_s = false, to_a = false;
+                uint32_t id = 0u;
+                if (i < nH) {
+                    id = LH[i];
+                    uint32_t* f = F + id;
+                    Shade vs;
+                    vs.pt = rec_v3_load(f + SF_O * LM_CAP, LM_CAP); vs.wo = rec_v3_load(f + SF_WO * LM_CAP, LM_CAP);
+                    const float val = u2f(f[SF_VAL * LM_CAP]);
+                    Rng rng;
+                    rec_rng_load(f + SF_RNG * LM_CAP, LM_CAP, rng);
+                    Nee ne;
+                    shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
+                    rec_rng_store(f + SF_RNG * LM_CAP, LM_CAP, rng);
+                    if (!last) {                                            // what sample_bsdf needs of the event
+                        rec_v3_store(f + SF_GRAD * LM_CAP, LM_CAP, vs.gradient);
+                        f[SF_COLOR * LM_CAP] = f2u(vs.color[0]); f[(SF_COLOR + 1) * LM_CAP] = f2u(vs.color[1]); f[(SF_COLOR + 2) * LM_CAP] = f2u(vs.color[2]);
+                        f[SF_PBRDF * LM_CAP] = f2u(vs.Pbrdf);
+                    }
+                    f[SF_META * LM_CAP] = (ne.light << 4) | (vs.st ? 0x100u : 0u);
+                    if (ne.have) {
+                        rec_v3_store(f + SF_D * LM_CAP, LM_CAP, ne.wi);
+                        rec_v3_store(f + SF_B * LM_CAP, LM_CAP, ne.B);
+                        f[SF_PDF * LM_CAP] = f2u(ne.pdf);
+                        to_s = true;
+                    } else if (last) {                                      // no light sample reaches the event and nothing follows: L is final
+                        const v3 L = rec_v3_load(f + SF_L * LM_CAP, LM_CAP);
+                        float* p = gpend + (id >> 6) * (3u * 64u) + (id & 63u);
+                        p[0] = L.x; p[64] = L.y; p[128] = L.z;
+                    } else to_a = true;
+                }
+                const uint64_t ms = __ballot(to_s), ma = __ballot(to_a);
+                if (to_s) LS[nS + lane_rank(ms)] = id;
+                if (to_a) LA[nA + lane_rank(ma)] = id;
+                nS += (uint32_t)__popcll(ms); nA += (uint32_t)__popcll(ma);
+            }
+            // ---- walk: the shadow rays -> A (or final, at the last bounce) ----
+            fence();
+            lm_walk_pool_deep<LAYOUT, COUNT>(s, lds, F, LS, nS, LMK_SHADOW, last, LA, nA, gpend, c);
+            fence();
+            nW = 0u;
+            if (last) break;
+            // ---- sample_bsdf, throughput, roulette (pathtracer.cu:258-276), 64 at a time -> the next bounce's rays ----
+            for (uint32_t i0 = 0u; i0 < nA; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                bool to_w = false;
+                uint32_t id = 0u;
+                if (i < nA) {
+                    id = LA[i];
+                    uint32_t* f = F + id;
+                    Shade vs;
+                    vs.pt = rec_v3_load(f + SF_O * LM_CAP, LM_CAP); vs.wo = rec_v3_load(f + SF_WO * LM_CAP, LM_CAP);
+                    vs.gradient = rec_v3_load(f + SF_GRAD * LM_CAP, LM_CAP);
+                    vs.color[0] = u2f(f[SF_COLOR * LM_CAP]); vs.color[1] = u2f(f[(SF_COLOR + 1) * LM_CAP]); vs.color[2] = u2f(f[(SF_COLOR + 2) * LM_CAP]); vs.color[3] = 0.f;
+                    vs.Pbrdf = u2f(f[SF_PBRDF * LM_CAP]);
+                    vs.st = (f[SF_META * LM_CAP] & 0x100u) ? 1 : 0;
+                    v3 T = rec_v3_load(f + SF_T * LM_CAP, LM_CAP);
+                    Rng rng;
+                    rec_rng_load(f + SF_RNG * LM_CAP, LM_CAP, rng);
+                    v3 wi; float pdf = 0.f;
+                    const v3 fr = bsdf_sample(vs, wi, pdf, rng);
+                    const float cosTerm = __builtin_fabsf(dot(normalize(vs.gradient), wi));
+                    if (fmax_(fr.x, fmax_(fr.y, fr.z)) > 0.f && pdf > 0.f) {
+                        if (vs.st == 0) T = T * (fr / (pdf * (1.f - vs.Pbrdf)));
+                        else T = T * ((fr * cosTerm) / (pdf * vs.Pbrdf));
+                    }
+                    if (k >= 3u && russian_roulette(T, rng)) {              // the path ends: L is final
+                        const v3 L = rec_v3_load(f + SF_L * LM_CAP, LM_CAP);
+                        float* p = gpend + (id >> 6) * (3u * 64u) + (id & 63u);
+                        p[0] = L.x; p[64] = L.y; p[128] = L.z;
+                    } else {
+                        rec_v3_store(f + SF_D * LM_CAP, LM_CAP, wi);        // (the next ray starts at the event: SF_O already holds it)
+                        rec_v3_store(f + SF_T * LM_CAP, LM_CAP, T);
+                        rec_rng_store(f + SF_RNG * LM_CAP, LM_CAP, rng);
+                        to_w = true;
+                    }
+                }
+                const uint64_t mw = __ballot(to_w);
+                if (to_w) LW[nW + lane_rank(mw)] = id;
+                nW += (uint32_t)__popcll(mw);
+            }
+        }
+        // ---- fold the batch ----
+        fence();
+        fold_pending(s, w, gpend, 64u, &pend_task[wave][0], nb);
+        fence();
+    }
+    if (COUNT) cnt_flush(w, c);
+}
+
 // Persistent 1024-thread blocks, one task = (64 >> f) pixels x (1 << f) frames per wave from 8 sharded tickets, centre-out
 // order, the frames of a launch folded into the accumulator in the kernel (svr_tile_tasks.hpp) -- the work distribution of
 // k_trace_tile (svr_trace_tile.hip has the measurements behind it).  The radiance of up to QUEUE_TASKS tasks waits in the
@@ -746,6 +1092,7 @@ static hipError_t launch_lm_t(const DevScene& s, const DevWork& w, const LaunchC
     if (e != hipSuccess) return e;
     // traceDepth 1 (the reference's default), folding launch, queue memory at hand: the pool form
     if (w.traceDepth == 1u && w.fold && w.queue != nullptr && !cfg.lm_straight) hipLaunchKernelGGL((k_trace_lm_pool<LAYOUT, COUNT>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
+    else if (w.traceDepth > 1u && w.fold && w.queue != nullptr && !cfg.lm_straight) hipLaunchKernelGGL((k_trace_lm_pool_deep<LAYOUT, COUNT>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
     else if (w.traceDepth == 1u) hipLaunchKernelGGL((k_trace_lm<LAYOUT, COUNT, true>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
     else hipLaunchKernelGGL((k_trace_lm<LAYOUT, COUNT, false>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
     return hipGetLastError();

@@ -203,13 +203,14 @@ def test_local_majorant_is_a_pure_function_of_scene_pixel_frame(hip_dev, name, d
         canvas.close()
 
 
-@pytest.mark.parametrize("name", ["c3", "c3n"])
-def test_local_majorant_pool_equals_straight_line_full_frame(hip_dev, name):
-    """traceDepth 1 folding launches run the POOL form of the kernel (a wave takes a batch of 16 tasks through gen / walk pool /
-    batched shading / walk pool / fold, csrc/svr_trace_lm.hip); SVR_OPT_LOCAL_MAJORANT = 2 forces the straight-line form.
-    Scheduling only: bit-identical on the whole 1024^2 frame, one 128-frame call (two 64-frame launches: a wave = one pixel x
-    64 frames, shared whole-ray tests) and one 24-frame call (2 pixels x 32 frame lanes, 8 of them dead, per-lane tests)."""
-    sc, canvas = _canvas(hip_dev, name, trace_depth=1)
+@pytest.mark.parametrize("name,depth", [("c3", 1), ("c3n", 1), ("c3", 2), ("c3", 5), ("c3n", 4)])
+def test_local_majorant_pool_equals_straight_line_full_frame(hip_dev, name, depth):
+    """Folding launches run the POOL forms of the kernel (a wave takes a batch of 16 tasks through gen / walk pool / batched
+    shading / walk pool / [batched BSDF sampling / ...] / fold, csrc/svr_trace_lm.hip: records at traceDepth 1, one slot per
+    path beyond); SVR_OPT_LOCAL_MAJORANT = 2 forces the straight-line form.  Scheduling only: bit-identical on the whole 1024^2
+    frame, one 128-frame call (two 64-frame launches: a wave = one pixel x 64 frames, shared whole-ray tests) and one 24-frame
+    call (2 pixels x 32 frame lanes, 8 of them dead, per-lane tests)."""
+    sc, canvas = _canvas(hip_dev, name, trace_depth=depth)
     dev = hip_dev
     try:
         for n in (128, 24):
@@ -219,7 +220,7 @@ def test_local_majorant_pool_equals_straight_line_full_frame(hip_dev, name):
                 canvas.ReStartRender()
                 canvas.paint_frames(n, sync=True)
                 imgs.append((canvas.read_hdr(), canvas.read_img()))
-            assert_bit_exact(imgs[0][0], imgs[1][0], f"{name}: pool vs straight-line local-majorant paths, {n} frames")
+            assert_bit_exact(imgs[0][0], imgs[1][0], f"{name} depth {depth}: pool vs straight-line local-majorant paths, {n} frames")
             assert np.array_equal(imgs[0][1], imgs[1][1])
             assert imgs[0][0].max() > 0
     finally:

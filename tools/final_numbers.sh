@@ -1,15 +1,16 @@
 #!/bin/bash
-# The numbers DESIGN.md quotes, in one GPU call: every BASELINE config, depths, protocol variants, ray caster.
+# The numbers DESIGN.md quotes, in one GPU call: every BASELINE config in the default (bit-exact) and the local-majorant mode,
+# depths, protocol variants, ray caster.  usage: tools/final_numbers.sh <tag>
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 OUT=gpurun_out/${1:-final}_numbers.log
 : > $OUT
-for sc in c2 c3 c4 c5; do timeout -k 10 300 python tools/sweep.py --scene $sc --frames 128 --spp 128 --count defaults 2>&1 | tee -a $OUT; done
-for d in 2 4 6; do timeout -k 10 300 python tools/sweep.py --scene c3 --depth $d --frames 128 --spp 128 defaults queue=0 queue=2 2>&1 | tee -a $OUT; done
-timeout -k 10 300 python tools/sweep.py --scene c3 --frames 256 --spp 256 defaults fast_math=1 fold=0 empty_skip=0 2>&1 | tee -a $OUT
-timeout -k 10 300 python tools/sweep.py --scene c3 --frames 256 --spp 256 --layout 2 defaults empty_skip=0 2>&1 | tee -a $OUT
+for sc in c2 c3 c3n c4 c5; do timeout -k 10 300 python tools/sweep.py --scene $sc --frames 256 --spp 256 --count defaults lm=1 2>&1 | tee -a $OUT; done
+for d in 2 4 6; do timeout -k 10 300 python tools/sweep.py --scene c3 --depth $d --frames 128 --spp 128 defaults queue=0 lm=1 2>&1 | tee -a $OUT; done
+timeout -k 10 300 python tools/sweep.py --scene c3n --depth 4 --frames 128 --spp 128 defaults lm=1 2>&1 | tee -a $OUT
+timeout -k 10 300 python tools/sweep.py --scene c3 --frames 256 --spp 256 defaults fast_math=1 queue=0 empty_skip=0 light_cull=0 2>&1 | tee -a $OUT
+for lay in 2 3; do timeout -k 10 300 python tools/sweep.py --scene c3 --frames 256 --spp 256 --layout $lay defaults empty_skip=0 2>&1 | tee -a $OUT; done
 timeout -k 10 300 python tools/sweep.py --scene c3 --frames 64 --spp 1 defaults frame_ahead=0 2>&1 | tee -a $OUT
-for d in 1 4; do timeout -k 10 300 python tools/sweep.py --scene c3n --depth $d --frames 128 --spp 128 --count defaults queue=0 bound_cull=0,queue=0 fast_math=1 2>&1 | tee -a $OUT; done
-timeout -k 10 300 python tools/sweep.py --scene c3 --frames 256 --spp 256 --shard 16,3,8 defaults group=32 2>&1 | tee -a $OUT
+timeout -k 10 300 python tools/sweep.py --scene c3 --frames 256 --spp 256 --shard 16,3,8 defaults 2>&1 | tee -a $OUT
 timeout -k 10 300 python tools/raycast_time.py 2>&1 | tee -a $OUT
