@@ -344,7 +344,7 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
         begin_walk(true, k + 1u < traceDepth);
     };
 
-    const uint32_t park_cheap = SVR_PARK_CHEAP;
+    const uint32_t park_cheap = s.park_cheap;          // (SVR_OPT_PARK_CHEAP; SVR_PARK_CHEAP = 16 is the default)
     if constexpr (DEPTH1) {
         // traceDepth 1: the machine only walks -- pop a shaded event, shadow walk, radiance -- so its rounds are cheap
         // (~10^2 instructions) and run as soon as a few lanes wait
