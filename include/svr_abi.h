@@ -260,6 +260,8 @@ int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_loc
                                      * consumes (another, equally valid estimate), so it is part of the mode's definition, not a speed-only switch */
 #define SVR_OPT_PARK_CHEAP 27       /* lane machine of the tile kernel at traceDepth 1: ended shadow walks + idle lanes with a record waiting before the wave
                                      * settles / refills them (1..64, default 16).  Speed only */
+#define SVR_OPT_PINHOLE_FAST 28     /* 1 (default): with apeture == 0 (the reference's default) the camera ray skips the square root and the sine / cosine of
+                                     * the lens sample, which is (+-0, +-0) and provably changes no bit of the ray; the draws are consumed.  Results unchanged */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */

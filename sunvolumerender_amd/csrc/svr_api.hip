@@ -121,7 +121,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -298,6 +298,19 @@ int build_scene(const svr_volume& vol, const svr_transfer_function& tf, const sv
     s.aspectRatio = cam.aspectRatio; s.tanFovxOverTwo = cam.tanFovxOverTwo;
     s.wm1 = (float)cam.imageW - 1.f;
     s.hm1 = (float)cam.imageH - 1.f;
+    {
+        // cudaCamera::GenerateRay with apeture == +0 (the reference's default, gui/canvas.h:218): lens sample = (cos(theta) * 0, sin(theta) * 0)
+        // = (+-0, +-0).  orig = pos + u * (+-0) + v * (+-0) is pos bit for bit unless a component of pos is -0 (-0 + +0 = +0); the image-plane
+        // coordinates are +0 or non-zero when their scales are positive, so subtracting +-0 changes nothing.  Then the kernels may skip the
+        // sqrt and the sincos of the lens sample (the two draws are still consumed).
+        uint32_t ap_bits, p_bits[3];
+        memcpy(&ap_bits, &cam.apeture, 4);
+        memcpy(p_bits, &cam.pos, 12);
+        const float scale_x = cam.aspectRatio * cam.tanFovxOverTwo * cam.focalLength, scale_y = cam.tanFovxOverTwo * cam.focalLength;
+        s.cam_pinhole = (g.opt_pinhole_fast && ap_bits == 0u && p_bits[0] != 0x80000000u && p_bits[1] != 0x80000000u && p_bits[2] != 0x80000000u &&
+                         cam.aspectRatio > 1e-20f && cam.tanFovxOverTwo > 1e-20f && cam.focalLength > 1e-20f && scale_x > 1e-20f && scale_y > 1e-20f &&
+                         std::isfinite(scale_x) && std::isfinite(scale_y)) ? 1u : 0u;
+    }
     s.cam_pos[0] = cam.pos.x; s.cam_pos[1] = cam.pos.y; s.cam_pos[2] = cam.pos.z;
     s.cam_u[0] = cam.u.x; s.cam_u[1] = cam.u.y; s.cam_u[2] = cam.u.z;
     s.cam_v[0] = cam.v.x; s.cam_v[1] = cam.v.y; s.cam_v[2] = cam.v.z;
@@ -1393,6 +1406,7 @@ int svr_set_option(int key, int value)
     case SVR_OPT_QUEUE:
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_QUEUE: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_queue = value; g.queue_alloc_failed = false; return 0;
+    case SVR_OPT_PINHOLE_FAST: g.opt_pinhole_fast = value ? 1 : 0; return 0;
     case SVR_OPT_PARK_CHEAP:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_CHEAP: bad value %d (1..64)", value);
         g.opt_park_cheap = value; return 0;
@@ -1443,6 +1457,7 @@ int svr_get_option(int key)
     case SVR_OPT_QUEUE: return g.opt_queue;
     case SVR_OPT_PARK_END: return g.opt_park_end;
     case SVR_OPT_PARK_CHEAP: return g.opt_park_cheap;
+    case SVR_OPT_PINHOLE_FAST: return g.opt_pinhole_fast;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     case SVR_OPT_FRAMES_PER_WAVE_LOG2: return g.opt_frames_log2;
     case SVR_OPT_RAYCAST_LANES_LOG2: return g.opt_rc_lanes;

@@ -316,7 +316,14 @@ SVR_DEV void camera_ray(const DevScene& s, uint32_t x, uint32_t y, Rng& rng, v3&
     nx = nx * s.focalLength;
     ny = ny * s.focalLength;
     float ax, ay;
-    uniform_sample_disk(rng, s.apeture, ax, ay);
+    if (s.cam_pinhole) {
+        // apeture == +0: the lens sample is (cos * 0, sin * 0) = (+-0, +-0), and with no -0 in the camera position and positive
+        // image-plane scales (checked on the host) adding / subtracting it changes no bit of orig or dir.  The two draws are
+        // still consumed (sampling.h:26-32).
+        rng_skip(rng); rng_skip(rng);
+        ax = 0.f; ay = 0.f;
+    } else
+        uniform_sample_disk(rng, s.apeture, ax, ay);
     v3 cu = V3(s.cam_u[0], s.cam_u[1], s.cam_u[2]);
     v3 cv = V3(s.cam_v[0], s.cam_v[1], s.cam_v[2]);
     v3 cw = V3(s.cam_w[0], s.cam_w[1], s.cam_w[2]);

@@ -67,6 +67,7 @@ struct DevScene {
     uint32_t imageW, imageH;
     float exposure, apeture, focalLength, aspectRatio, tanFovxOverTwo;
     float wm1, hm1;                // imageW - 1.f, imageH - 1.f
+    uint32_t cam_pinhole;          // 1: apeture is +0 and the lens sample provably cannot change a bit of the ray (svr_api.hip): camera_ray skips its sqrt / sincos
     float cam_pos[3], cam_u[3], cam_v[3], cam_w[3];
     // ---- cudaEnvironmentLight ----
     const float* env;              // env_h x env_w x float4, or null

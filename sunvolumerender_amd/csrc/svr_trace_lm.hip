@@ -19,6 +19,9 @@
 // What is NOT preserved: the consumption of random numbers -- a path's radiance is no longer the oracle's bit for bit.
 // The contract of this mode is therefore the converged-image tolerance of tests/test_local_majorant_gpu.py, like
 // SVR_OPT_FAST_MATH.  Everything else (camera, shading, lights, BSDF, accumulation) is the bit-exact code.
+//
+// Three forms of one algorithm, bit-identical to each other: straight-line paths (k_trace_lm: non-folding launches, cross-check),
+// the record pool of traceDepth 1 (k_trace_lm_pool) and the slot-per-path pool of deeper paths (k_trace_lm_pool_deep).
 #include "svr_walk.hpp"
 #include "svr_lanes.hpp"
 #include "svr_tile_tasks.hpp"

@@ -357,6 +357,26 @@ def test_raycasting_lanes_per_ray(hip_dev, lanes_log2):
         assert cnt["raycast_steps"] == rc["raycast_steps"]
 
 
+def test_pinhole_camera_fast_path(hip_dev):
+    """With apeture == 0 (the reference's default) the lens sample is (+-0, +-0) and camera_ray skips its square root and sine / cosine
+    (SVR_OPT_PINHOLE_FAST): the oracle's image bit for bit with the switch on and off, with a camera position that holds a -0 component
+    (where +-0 can flip a sign bit, so the library must not take the fast path), and off the optical axis."""
+    base = scenes.make_scene("tiny_head", trace_depth=2)
+    eye = host.zoom_to_extent_eye_dist(host.volume_size(base.dim, base.spacing), base.fov)
+    cams = [None,
+            host.camera_setup((-0.0, 0.0, eye), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), base.fov, 0.0, 1.0, 1.0, base.width, base.height),
+            host.camera_setup((0.3 * eye, -0.0, 0.8 * eye), (1.0, 2.0, 0.0), (0.0, 1.0, 0.1), 38.0, 0.0, 2.5, 1.0, base.width, base.height)]
+    for cam in cams:
+        sc = dataclasses.replace(base, camera=cam)
+        ref_hdr, ref_img, _ = oracle_frames(sc, 4)
+        for fast in (1, 0):
+            hip_dev.set_option(abi.OPT_PINHOLE_FAST, fast)
+            hdr, img, _ = hip_frames(hip_dev, sc, 4, batch=True)
+            assert_bit_exact(hdr, ref_hdr, f"pinhole camera, fast path {fast}, camera {cam is not None}")
+            assert np.array_equal(img, ref_img)
+    hip_dev.set_option(abi.OPT_PINHOLE_FAST, 1)
+
+
 @pytest.mark.parametrize("apeture", [0.0, 2.5])
 def test_lights_in_and_around_the_view_frustum(hip_dev, apeture):
     """SVR_OPT_LIGHT_CULL drops lights no camera ray can reach from the primary rays' nearest-light test (a conservative
