@@ -47,6 +47,7 @@ struct LaunchCfg {
     int unit_override;     // tile kernel: tasks per ticket (0 = heuristic)
     int frames_log2;       // tile kernel: log2(frames per wave), -1 = as many as the group allows (<= 8)
     bool lm_straight;      // local-majorant kernel: straight-line paths also where the pool form applies (cross-check)
+    bool pool_primary;     // tile kernel, QUEUE builds at traceDepth 1: the primary walks go through the lane machine too (POOL)
 };
 
 // trace work.nframes paths per owned pixel into the scratch slots work.lbuf

@@ -173,6 +173,20 @@ SVR_DEV uint32_t rec_c1_load(const uint32_t* p, uint32_t cap, v3& pt, Nee& ne, R
     ne.light = meta_light(meta);
     return meta;
 }
+// P (traceDepth 1, POOL builds): a camera ray that has something possibly occupied ahead, waiting for its primary walk -- in the words
+// of a C1 record: origin, direction, (nearest light's t, first possibly-occupied parameter, tMin), tMax, generator, id | nearest light + 1
+SVR_DEV void rec_p_store(uint32_t* p, uint32_t cap, v3 o, v3 d, float ls_t, float t_occ, float tMin, float tMax, const Rng& rng, uint32_t id, uint32_t ls1)
+{
+    rec_v3_store(p, cap, o); rec_v3_store(p + 3 * cap, cap, d);
+    p[6 * cap] = f2u(ls_t); p[7 * cap] = f2u(t_occ); p[8 * cap] = f2u(tMin); p[9 * cap] = f2u(tMax);
+    rec_rng_store(p + 10 * cap, cap, rng);
+    p[16 * cap] = rec_meta(id, 0u, ls1, 0);
+}
+// H (POOL builds): the collision of a primary walk, waiting to be shaded: pt(3) wo(3) val rng(6) id
+constexpr uint32_t REC_H_WORDS = 14;
+SVR_DEV uint32_t* queue_h(const LaneQueue& Q) { return Q.q + (size_t)REC_C1_WORDS * Q.cap; }
+static_assert(REC_C1_WORDS + REC_H_WORDS <= REC_WORDS, "P / C1 records and H records share a wave's queue slice");
+
 // the wave's queue memory: traceDepth 1: C1 records; deeper: stacks A | B
 SVR_DEV uint32_t* queue_c(const LaneQueue& Q) { return Q.q; }
 SVR_DEV uint32_t* queue_a(const LaneQueue& Q) { return Q.q; }
@@ -218,9 +232,11 @@ SVR_DEV void queue_push_a(const LaneQueue& Q, uint32_t& nA, bool live, const Sha
 // Drain the wave's records (traceDepth 1: nC shaded first events; deeper: nA paths waiting for the BSDF sampling, nB0 for the shading) with all 64 lanes.  pendL: the
 // wave's pending-radiance rows ([task * 3 + channel] of pend_row floats); a finished path with id = (task << 6 | lane)
 // stores its radiance at row (id >> 6) * 3 + channel, column id & 63.
-template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS>
+// POOL builds (traceDepth 1): `primary` = the records are P records (camera rays): a lane pops one, walks it, and settles it --
+// the nearest light or the environment (the path is over) or a collision, which becomes an H record (nH counts them).
+template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS, bool POOL = false>
 SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, uint32_t nC, uint32_t nA, uint32_t nB0, uint32_t traceDepth_, float* pendL, uint32_t pend_row, Cnt& c,
-                         unsigned long long* c_prof = nullptr)
+                         unsigned long long* c_prof = nullptr, const bool primary = false, uint32_t* nH = nullptr)
 {
     enum : uint32_t { IDLE = 0u, CELL = 1u, WALK = 2u, FETCH = 3u, MARCH = 4u, END = 5u, WANT_A = 6u, WANT_B = 7u };
     const float INF = u2f(SVR_INF_BITS);
@@ -363,14 +379,57 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
             }
             PROF_END(pw, 32u);
             PROF_BEGIN(pe, PH_END);
-            if (st == END) { nee(); finish(); }
+            if (POOL && primary) {
+                // the end of a primary walk (pathtracer.cu:220-235): the nearest light in front of the collision, no collision: the
+                // environment -- the path is over -- else a scatter event for the wave to shade (H record)
+                bool to_hit = false;
+                if (st == END) {
+                    const float tt = hit ? t : SVR_FLT_MAX;
+                    const uint32_t ls1 = ne.light;                          // nearest light + 1 (0 = none); ne.pdf holds its t
+                    if (ls1 != 0u && ne.pdf < tt) {
+                        const DevLight& l = s.lights[ls1 - 1u];
+                        const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -dir);
+                        L = L + (T * V3(l.radiance[0], l.radiance[1], l.radiance[2])) * (cosTerm <= 0.f ? 0.f : 1.f);
+                        finish();
+                    } else if (!hit) {
+                        if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+                        finish();
+                    } else to_hit = true;
+                }
+                const uint64_t mh = __ballot(to_hit);
+                if (to_hit) {
+                    uint32_t* h = queue_h(Q) + *nH + lane_rank(mh);
+                    rec_v3_store(h, Q.cap, orig + dir * t); rec_v3_store(h + 3 * Q.cap, Q.cap, -dir);
+                    h[6 * Q.cap] = f2u(val);
+                    rec_rng_store(h + 7 * Q.cap, Q.cap, rng);
+                    h[13 * Q.cap] = id;
+                    st = IDLE;
+                }
+                *nH += (uint32_t)__popcll(mh);
+            } else if (st == END) { nee(); finish(); }
             if (next < nC) {
                 const uint64_t idle = __ballot(st == IDLE);
                 const uint32_t i = next + lane_rank(idle);
                 if (st == IDLE && i < nC) {
-                    id = meta_id(rec_c1_load(queue_c(Q) + i, Q.cap, vs.pt, ne, rng));
-                    L = V3(0.f, 0.f, 0.f); T = V3(1.f, 1.f, 1.f); k = 0u;
-                    begin_shadow();
+                    if (POOL && primary) {
+                        // a P record: the walk's set-up was done when the ray was generated (box, shared whole-ray test)
+                        const uint32_t* r = queue_c(Q) + i;
+                        orig = rec_v3_load(r, Q.cap); dir = rec_v3_load(r + 3 * Q.cap, Q.cap);
+                        ne.pdf = u2f(r[6 * Q.cap]); t_occ = u2f(r[7 * Q.cap]); tMin = u2f(r[8 * Q.cap]); tMax = u2f(r[9 * Q.cap]);
+                        rec_rng_load(r + 10 * Q.cap, Q.cap, rng);
+                        const uint32_t meta = r[16 * Q.cap];
+                        id = meta_id(meta); ne.light = meta_light(meta);
+                        L = V3(0.f, 0.f, 0.f); T = V3(1.f, 1.f, 1.f); k = 0u;
+                        shadow = false; rng_live = false; hit = false;
+                        t = tMin; clear_run = 0u; guard = 0u; tail_counted = false;
+                        ray_skippable = SKIP && s.ray_skip && t_occ == INF;          // (counting builds only: the others never queue such a ray)
+                        if (COUNT && ray_skippable) c.wskip++;
+                        st = WALK;
+                    } else {
+                        id = meta_id(rec_c1_load(queue_c(Q) + i, Q.cap, vs.pt, ne, rng));
+                        L = V3(0.f, 0.f, 0.f); T = V3(1.f, 1.f, 1.f); k = 0u;
+                        begin_shadow();
+                    }
                 }
                 next = min(nC, next + (uint32_t)__popcll(idle));
             }

@@ -195,6 +195,39 @@ SVR_DEV bool trace_primary(const DevScene& s, const LDS& L_, uint32_t x, uint32_
     return true;
 }
 
+// POOL builds: trace_primary up to the walk -- generator, camera ray, nearest light, box, whole-ray test.  true = the ray has a walk to do
+// (orig / dir / tMin / tMax / t_occ / ls_* describe it: a P record, svr_lanes.hpp); false = the path is over with its radiance in L.
+template <bool COUNT, bool SKIP, typename LDS>
+SVR_DEV bool gen_primary(const DevScene& s, const LDS& L_, uint32_t x, uint32_t y, uint32_t hashed, bool group_march, uint32_t P2, GroupMapShared* gslot,
+                         Cnt& c, Rng& rng, v3& L, v3& orig, v3& dir, float& tMin, float& tMax, float& t_occ, float& ls_t, int& ls_id)
+{
+    uint32_t offset = y * s.imageW + x;
+    rng_init(rng, hashed + offset);
+    if (COUNT) c.paths++;
+    L = V3(0.f, 0.f, 0.f);
+    const v3 T = V3(1.f, 1.f, 1.f);
+    camera_ray(s, x, y, rng, orig, dir);
+    ls_id = nearest_light(s, orig, dir, ls_t);
+    tMin = (float)1e-6; tMax = SVR_FLT_MAX;
+    int r;
+    if (SKIP && group_march) {
+        GroupMap map;
+        map.g = gslot + ((threadIdx.x & 63u) & ((1u << P2) - 1u) & (GROUP_MAPS_PER_WAVE - 1u));
+        r = walk_setup_group<COUNT, SKIP>(s, L_, P2, orig, dir, false, tMin, tMax, t_occ, map);
+    } else
+        r = walk_setup<COUNT, SKIP>(s, L_, orig, dir, false, tMin, tMax, t_occ);
+    if (r > 0) return true;
+    // no walk: the result of sample_distance is -FLT_MAX (pathtracer.cu:220-235 with t < 0)
+    if (ls_id >= 0) {
+        const DevLight& l = s.lights[ls_id];
+        float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -dir);
+        L = L + (T * V3(l.radiance[0], l.radiance[1], l.radiance[2])) * (cosTerm <= 0.f ? 0.f : 1.f);
+        return false;
+    }
+    if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+    return false;
+}
+
 #ifndef SVR_TILE_WAVES_PER_EU
 #define SVR_TILE_WAVES_PER_EU 4
 #endif
@@ -219,9 +252,14 @@ struct LdsPendQueue {                              // QUEUE builds: only the tas
     uint32_t task[TILE_WAVES][QUEUE_TASKS];
 };
 
-template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, bool QUEUE>
+// POOL (QUEUE builds at traceDepth 1, media where the primary walks of a wave are NOT coherent -- fog-like data without exactly
+// transparent space, c3n): the primary walks are pooled too.  A task only generates its camera rays (P records); at a flush the lane
+// machine walks them (a lane pops a ray, walks, settles, pops the next), the collisions are shaded 64 at a time into C1 records, and
+// the machine walks those -- the wave-sized wavefront of svr_trace_lm.hip with the bit-exact walk.  Scheduling only.
+template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, bool QUEUE, bool POOL = false>
 __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_trace_tile(const DevScene s, const DevWork w)
 {
+    static_assert(!POOL || (QUEUE && DEPTH1 && SKIP), "the pool form exists for traceDepth 1 with the queue machine");
     using LDS = typename std::conditional<SKIP, LdsTileCull, LdsTileNoMask>::type;
     __shared__ LDS lds;
     __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
@@ -260,6 +298,40 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
         if constexpr (QUEUE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // records and radiance are read back by other lanes of this wave
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if constexpr (POOL) {
+                // qC camera rays (P records) -> collisions (H records) -> shaded, 64 at a time -> C1 records -> their shadow walks
+                uint32_t nH = 0u;
+                drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, true>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                qC = 0u;
+                for (uint32_t i0 = 0u; i0 < nH; i0 += 64u) {
+                    const uint32_t i = i0 + lane;
+                    bool have = false;
+                    Shade vs;
+                    vs.pt = V3(0.f, 0.f, 0.f); vs.wo = vs.pt; vs.gradient = vs.pt; vs.color[0] = vs.color[1] = vs.color[2] = vs.color[3] = 0.f; vs.Pbrdf = 0.f; vs.st = 0;
+                    Nee ne;
+                    ne.wi = vs.pt; ne.B = vs.pt; ne.pdf = 1.f; ne.light = 0u; ne.have = false;
+                    Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
+                    uint32_t id = 0u;
+                    if (i < nH) {
+                        const uint32_t* h = queue_h(Q) + i;
+                        vs.pt = rec_v3_load(h, Q.cap); vs.wo = rec_v3_load(h + 3 * Q.cap, Q.cap);
+                        const float val = u2f(h[6 * Q.cap]);
+                        rec_rng_load(h + 7 * Q.cap, Q.cap, rng);
+                        id = h[13 * Q.cap];
+                        shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
+                        have = ne.have;
+                        if (!have) {                                          // a first event no light sample reaches: L = 0
+                            float* o = gpend + (id >> 6) * (3u * 64u) + (id & 63u);
+                            o[0] = 0.f; o[64] = 0.f; o[128] = 0.f;
+                        }
+                    }
+                    queue_push_c1(Q, qC, have, vs.pt, ne, rng, id);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
             drain_queue<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, Q, qC, qA, qB, w.traceDepth, gpend, 64u, c, w.counters + CNT_N);
             qC = qA = qB = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -318,7 +390,29 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 const bool live = px < wv && r < w.n_rows && slot < w.nframes;
                 // shared whole-ray test: >= 8 frames of a pixel in the wave, every lane alive (the group shuffles)
                 const bool group_march = SKIP && fl2 >= 3u && (!SVR_DEBUG_STOPS || w.debug_stop == 0u || w.debug_stop >= 3u) && __ballot(live) == ~0ull;
-                if constexpr (QUEUE) {
+                if constexpr (POOL) {
+                    Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
+                    v3 L = V3(0.f, 0.f, 0.f), orig = L, dir = V3(0.f, 0.f, 1.f);
+                    float tMin = 0.f, tMax = 0.f, t_occ = 0.f, ls_t = 0.f;
+                    int ls_id = -1;
+                    bool queued = false;
+                    if (live) {
+                        uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
+                        queued = gen_primary<COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, orig, dir, tMin, tMax, t_occ, ls_t, ls_id);
+                    }
+                    {
+                        const uint64_t m = __ballot(queued);
+                        if (queued) rec_p_store(queue_c(Q) + qC + lane_rank(m), Q.cap, orig, dir, ls_t, t_occ, tMin, tMax, rng, (npend << 6) | lane, (uint32_t)(ls_id + 1));
+                        qC += (uint32_t)__popcll(m);
+                    }
+                    if (!queued) {
+                        float* o = gpend + (size_t)npend * (3u * 64u) + lane;
+                        o[0] = L.x; o[64] = L.y; o[128] = L.z;
+                    }
+                    if (lane == 0) pend.task[wave][npend] = k;
+                    if (++npend == QUEUE_TASKS || qC + 64u > QUEUE_CAP) flush();
+                    continue;
+                } else if constexpr (QUEUE) {
                     // primary walk, then the hits' first scatter events are shaded in place -- the lanes are frames of the
                     // same pixels and scatter together.  traceDepth 1: the shaded events are queued for their shadow walks.
                     // Deeper: the shadow walk runs in place too (queueing it as well was slower: c3 depth 2 / 4, 4174 / 2602
@@ -458,6 +552,10 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
     const bool queue = LAYOUT != LAYOUT_LINEAR && w.fold && w.queue != nullptr && w.pend != nullptr && blocks <= w.queue_blocks && w.traceDepth < 32768u;   // a record's bounce counter has 15 bits
 #define SVR_LAUNCH_TILE(SK, D1, QU) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, SK, D1, QU>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2)
     if constexpr (LAYOUT != LAYOUT_LINEAR) {
+        if (queue && skip && d1 && cfg.pool_primary) {
+            hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, true, true, true, true>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2);
+            return hipGetLastError();
+        }
         if (queue) {
             if (skip && d1) SVR_LAUNCH_TILE(true, true, true);
             else if (skip) SVR_LAUNCH_TILE(true, false, true);

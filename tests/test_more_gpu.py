@@ -357,6 +357,26 @@ def test_raycasting_lanes_per_ray(hip_dev, lanes_log2):
         assert cnt["raycast_steps"] == rc["raycast_steps"]
 
 
+@pytest.mark.parametrize("name", ["tiny_head", "tiny_head_noisy", "small_head", "odd_thin_lens"])
+def test_pooled_primary_walks_bit_exact(hip_dev, name):
+    """SVR_OPT_POOL: at traceDepth 1 the queue machine can walk the PRIMARY rays too (a task only generates its camera rays as P
+    records; the lane machine walks them, the collisions are shaded 64 at a time into C1 records, the machine walks those) -- the
+    default for media without exactly transparent space.  Forced on (2) and off (0): the oracle's image and counters, production and
+    counting builds, one many-frame call (the pool rides on folding launches) of 40 frames (32 frame lanes, 8 dead) and of 64."""
+    sc = _odd_scene(depth=1) if name == "odd_thin_lens" else scenes.make_scene(name, trace_depth=1)
+    for nframes in (40, 64):
+        ref_hdr, ref_img, ref_c = oracle_frames(sc, nframes)
+        for pool in (2, 0):
+            hip_dev.set_option(abi.OPT_POOL, pool)
+            hip_dev.set_option(abi.OPT_QUEUE, 2)
+            hdr, img, c = hip_frames(hip_dev, sc, nframes, batch=True)
+            hip_dev.set_option(abi.OPT_QUEUE, 1)
+            assert_bit_exact(hdr, ref_hdr, f"{name}: pooled primary walks = {pool}, {nframes} frames")
+            assert np.array_equal(img, ref_img)
+            assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"] and c["scatter_events"] == ref_c["scatter_events"]
+    hip_dev.set_option(abi.OPT_POOL, 1)
+
+
 def test_pinhole_camera_fast_path(hip_dev):
     """With apeture == 0 (the reference's default) the lens sample is (+-0, +-0) and camera_ray skips its square root and sine / cosine
     (SVR_OPT_PINHOLE_FAST): the oracle's image bit for bit with the switch on and off, with a camera position that holds a -0 component
