@@ -29,8 +29,17 @@ from tests.util import assert_bit_exact
 pytestmark = pytest.mark.gpu
 
 
+def _make(name, **kw):
+    """named scenes, plus 'odd': non-cubic volume, anisotropic spacing (1, 0.5, 2), off-axis thin-lens camera, clip planes, density scale 1.2, the bone
+    transfer function (bound classes between 0 and 1), image size not a multiple of anything (tests/test_more_gpu.py::_odd_scene)"""
+    if name == "odd":
+        from tests.test_more_gpu import _odd_scene
+        return _odd_scene(depth=kw.get("trace_depth", 2))
+    return scenes.make_scene(name, **kw)
+
+
 def _canvas(dev, name, **kw):
-    sc = scenes.make_scene(name, **kw)
+    sc = _make(name, **kw)
     canvas = host.Canvas(dev, sc.width, sc.height)
     scenes.apply_to_canvas(sc, canvas)
     return sc, canvas
@@ -125,7 +134,7 @@ def test_local_majorant_unbiased_against_the_oracle(hip_dev):
         canvas.close()
 
 
-@pytest.mark.parametrize("name,depth", [("tiny_head", 1), ("tiny_head", 2), ("tiny_head_noisy", 1), ("tiny_bone", 2)])
+@pytest.mark.parametrize("name,depth", [("tiny_head", 1), ("tiny_head", 2), ("tiny_head_noisy", 1), ("tiny_bone", 2), ("odd", 1), ("odd", 3)])
 def test_local_majorant_means_agree_at_high_sample_counts(hip_dev, name, depth):
     """A bias of a few 0.1 % hides in the noise of 256 spp.  Small frames at 8192 spp, default mode against local-majorant mode:
     the per-channel means of the frame and of its four quadrants within 4 standard errors (estimated from two independent halves
@@ -150,7 +159,7 @@ def test_local_majorant_means_agree_at_high_sample_counts(hip_dev, name, depth):
         canvas.close()
 
 
-@pytest.mark.parametrize("name,depth", [("tiny_head", 1), ("tiny_head", 3), ("tiny_head_noisy", 2), ("small_head", 1)])
+@pytest.mark.parametrize("name,depth", [("tiny_head", 1), ("tiny_head", 3), ("tiny_head_noisy", 2), ("small_head", 1), ("odd", 1), ("odd", 4)])
 def test_local_majorant_is_a_pure_function_of_scene_pixel_frame(hip_dev, name, depth):
     """Inside the mode: one 24-frame call == 24 render_pathtracer calls (frames traced ahead, scratch slots + k_resolve) ==
     the counting build == the union of 3 row shards; and rendering twice gives the same bits."""
