@@ -248,7 +248,9 @@ int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_loc
                                      * (local) majorants instead of the reference's single global one (core/woodcock_tracking.h:29-31): same law of the
                                      * collision point, far fewer iterations, but a different consumption of random numbers.  NOT bit-identical to
                                      * the default mode; converged images agree within Monte-Carlo noise (tests/test_local_majorant_gpu.py).  Needs
-                                     * SVR_OPT_EMPTY_SKIP = 1 and clip planes inside the volume; otherwise the default kernel renders */
+                                     * SVR_OPT_EMPTY_SKIP = 1 and clip planes inside the volume; otherwise the default kernel renders.
+                                     * 1 = the pool kernels; 2 = the straight-line form of the same algorithm (identical results, slower: the
+                                     * reference the pool kernels are tested against) */
 #define SVR_OPT_LIGHT_CULL 24       /* 1 (default): area lights that no camera ray can reach (behind the lens plane or outside the view frustum, lens
                                      * and pixel jitter included; conservative host-side test) are skipped by the primary rays' nearest-light test
                                      * (core/lights/light_sample.h:23-49).  Results unchanged */
