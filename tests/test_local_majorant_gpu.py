@@ -237,6 +237,44 @@ def test_local_majorant_pool_equals_straight_line_full_frame(hip_dev, name, dept
         canvas.close()
 
 
+@pytest.mark.parametrize("name,depth", [("small_head", 1), ("small_head_noisy", 3), ("odd", 2)])
+def test_local_majorant_image_does_not_depend_on_scheduling_or_layout(hip_dev, name, depth):
+    """What is scheduling or storage stays scheduling or storage in this mode too: the pool's cells per turn and refill /
+    settle thresholds (SVR_OPT_LM_TUNE), the number of persistent blocks, the light culling, the pinhole fast path and the
+    four volume layouts give the same bits as the defaults (64-frame calls: the pool forms of the kernel)."""
+    dev = hip_dev
+    sc = _make(name, trace_depth=depth)
+    imgs = {}
+    for layout in (abi.LAYOUT_AUTO, abi.LAYOUT_LINEAR, abi.LAYOUT_BRICK, abi.LAYOUT_PAIR, abi.LAYOUT_CELL):
+        canvas = host.Canvas(dev, sc.width, sc.height)
+        scenes.apply_to_canvas(sc, canvas, layout)
+        try:
+            variants = [("defaults", [])]
+            if layout == abi.LAYOUT_AUTO:
+                variants += [("lm_tune 1/8/8", [(abi.OPT_LM_TUNE, 1 | (8 << 8) | (8 << 16))]), ("lm_tune 4/40/56", [(abi.OPT_LM_TUNE, 4 | (40 << 8) | (56 << 16))]),
+                             ("2 blocks per CU", [(abi.OPT_BLOCKS_PER_CU, 2)]), ("no light culling", [(abi.OPT_LIGHT_CULL, 0)]), ("no pinhole fast path", [(abi.OPT_PINHOLE_FAST, 0)])]
+            for what, opts in variants:
+                old = [(o, dev.lib.svr_get_option(o)) for o, _ in opts]
+                try:
+                    dev.set_option(abi.OPT_LOCAL_MAJORANT, 1)
+                    for o, v in opts:
+                        dev.set_option(o, v)
+                    canvas.ReStartRender()
+                    canvas.paint_frames(64, sync=True)
+                    imgs[(layout, what)] = (canvas.read_hdr(), canvas.read_img())
+                finally:
+                    for o, v in old:
+                        dev.set_option(o, v)
+                    dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
+        finally:
+            canvas.close()
+    ref = imgs[(abi.LAYOUT_AUTO, "defaults")]
+    assert ref[0].max() > 0
+    for key, (hdr, img) in imgs.items():
+        assert_bit_exact(hdr, ref[0], f"{name} depth {depth}, local majorants: layout {key[0]}, {key[1]}")
+        assert np.array_equal(img, ref[1])
+
+
 def test_local_majorant_falls_back_where_it_cannot_run(hip_dev):
     """Without the acceleration data (SVR_OPT_EMPTY_SKIP = 0) the switch is inert: the default kernel renders, bit-exact."""
     sc, canvas = _canvas(hip_dev, "tiny_head", trace_depth=2)
