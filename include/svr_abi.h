@@ -267,6 +267,9 @@ int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_loc
 #define SVR_OPT_POOL 29             /* tile kernel at traceDepth 1 with the queue machine: the primary walks are pooled too (a task only generates its camera
                                      * rays; the lane machine walks them, the collisions are shaded 64 at a time).  0 off, 1 (default) for media without
                                      * exactly transparent space (their walks are not coherent within a wave), 2 always.  Results unchanged */
+#define SVR_OPT_TRIPS 30            /* lane machine of the tile kernel (pooled walks at traceDepth 1, every walk of deeper paths): the walking lanes run FIVE
+                                     * Woodcock iterations per turn with the generator as a circular buffer (no register moves), a lane that needs a fetch waits
+                                     * for the end of the trip.  0 off, 1 (default) for media without exactly transparent space, 2 always.  Results unchanged */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */

@@ -121,7 +121,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -533,6 +533,8 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
     s.bound_cull = (g.opt_bound_cull == 2 || (g.opt_bound_cull == 1 && g.mask_cull_useful)) ? 1u : 0u;
     s.park_end = (uint32_t)g.opt_park_end;
     s.park_cheap = (uint32_t)g.opt_park_cheap;
+    // walks of tens of iterations with few fetches: media without exactly transparent space under bound culling (c3n: +18 %)
+    s.trips = (g.opt_trips == 2 || (g.opt_trips == 1 && s.bound_cull && !s.has_empty)) ? 1u : 0u;
     // pool tuning (same-box sweeps, gpurun_out/r03p_lm_tune.log): on the full-resolution grid (scenes with empty space) one cell per turn
     // (c3 9 920 / c5 8 430 Msamples/s against 9 480 / 7 630 with three), on the half-resolution grid of fog-like media three cells
     // and later refills (c3n 4 860 against 4 290 with one cell)
@@ -663,7 +665,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     if (local_majorant) use_queue = false;
     // POOL (svr_trace_tile.hip): pooled primary walks pay where the walks of a wave are not coherent -- media without exactly transparent
     // space under bound culling (c3n) -- and cost where they are (c3): auto = such media only
-    cfg.pool_primary = use_queue && rp->traceDepth == 1 && (g.opt_pool == 2 || (g.opt_pool == 1 && s.bound_cull && !s.has_empty));
+    cfg.pool_primary = use_queue && (g.opt_pool == 2 || (g.opt_pool == 1 && s.bound_cull && !s.has_empty));
     if (use_queue || (local_majorant && fold_batch)) {
         bool available = true;
         if (ensure_record_queues((uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / 16u, g.opt_queue == 1 && !local_majorant, available)) return g.err_code;
@@ -1414,6 +1416,9 @@ int svr_set_option(int key, int value)
     case SVR_OPT_POOL:
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_POOL: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_pool = value; return 0;
+    case SVR_OPT_TRIPS:
+        if (value < 0 || value > 2) return fail(-6, "SVR_OPT_TRIPS: bad value %d (0 off, 1 auto, 2 always)", value);
+        g.opt_trips = value; return 0;
     case SVR_OPT_PARK_CHEAP:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_CHEAP: bad value %d (1..64)", value);
         g.opt_park_cheap = value; return 0;
@@ -1466,6 +1471,7 @@ int svr_get_option(int key)
     case SVR_OPT_PARK_CHEAP: return g.opt_park_cheap;
     case SVR_OPT_PINHOLE_FAST: return g.opt_pinhole_fast;
     case SVR_OPT_POOL: return g.opt_pool;
+    case SVR_OPT_TRIPS: return g.opt_trips;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     case SVR_OPT_FRAMES_PER_WAVE_LOG2: return g.opt_frames_log2;
     case SVR_OPT_RAYCAST_LANES_LOG2: return g.opt_rc_lanes;

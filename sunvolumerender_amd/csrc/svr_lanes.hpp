@@ -234,7 +234,7 @@ SVR_DEV void queue_push_a(const LaneQueue& Q, uint32_t& nA, bool live, const Sha
 // stores its radiance at row (id >> 6) * 3 + channel, column id & 63.
 // POOL builds (traceDepth 1): `primary` = the records are P records (camera rays): a lane pops one, walks it, and settles it --
 // the nearest light or the environment (the path is over) or a collision, which becomes an H record (nH counts them).
-template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS, bool POOL = false>
+template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS, bool POOL = false, bool HIT_B = false>
 SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, uint32_t nC, uint32_t nA, uint32_t nB0, uint32_t traceDepth_, float* pendL, uint32_t pend_row, Cnt& c,
                          unsigned long long* c_prof = nullptr, const bool primary = false, uint32_t* nH = nullptr)
 {
@@ -295,6 +295,56 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
             xi = rng_uniform(rng);
             if (xi < ci.thr) st = FETCH;                   // else CULLED: xi >= bound >= sigma_t * invSigmaMax
             else if (COUNT) c.cull++;
+        }
+    };
+    // TRIPS (POOL builds: media without exactly transparent space, where a walk is tens of iterations long): five iterations of the
+    // walking lanes in a row with the generator as a circular buffer (svr_device.hpp: heads 0 2 4 1 3, no register moves, the
+    // Weyl word advanced once), the lanes that leave the WALK state on the way (FETCH / MARCH / END) recording after how many
+    // generator steps they left -- one barrel rotation behind the trip puts every generator back into the shifting form.  The
+    // operations of a lane are those of iterate(), in the same order: scheduling only.  A lane that left waits for the end of
+    // the trip (13 % of the iterations of c3n ask for a fetch: 3.85 of 5 iteration slots are used), and the fetch service runs
+    // once per trip for half of the lanes instead of once per iteration for an eighth.
+    auto iterate_rot = [&](auto hd, auto jj, bool& in, uint32_t& steps, const uint32_t d0) {
+        constexpr int H = decltype(hd)::value;
+        constexpr uint32_t J = (uint32_t)decltype(jj)::value;
+        if (!in) return;
+        if (COUNT) { c.iters++; if (ray_skippable || tail_counted) c.iskip++; }
+        t += -logf_unit(1.f - rng_to_uniform(rng_xorshift_rot<H>(rng) + (d0 + (2u * J + 1u) * RNG_WEYL))) * s.invSigmaMaxSI;
+        if (t > tMax || guard++ >= SVR_WALK_GUARD) { st = END; in = false; steps = 2u * J + 1u; return; }
+        if (COUNT) c.taps++;
+        if (SKIP && t < t_occ) {
+            if (COUNT && !(ray_skippable || tail_counted)) c.ipre++;
+            rng_xorshift_rot<(H + 1) % 5>(rng);
+            return;
+        }
+        const Cell cell = cell_of(s, orig + dir * t);
+        CellInfo ci;
+        ci.empty = false; ci.deep = false; ci.thr = INF;
+        if (SKIP) ci = cell_info<true>(L_, s, cell);
+        if (ci.empty) {
+            rng_xorshift_rot<(H + 1) % 5>(rng);
+            clear_run = ci.deep ? clear_run + 1u : 0u;
+            if (clear_run == 2u) { st = MARCH; in = false; steps = 2u * J + 2u; }
+        } else {
+            clear_run = 0u;
+            xi = rng_to_uniform(rng_xorshift_rot<(H + 1) % 5>(rng) + (d0 + (2u * J + 2u) * RNG_WEYL));
+            if (xi < ci.thr) { st = FETCH; in = false; steps = 2u * J + 2u; }
+            else if (COUNT) c.cull++;
+        }
+    };
+    auto trip = [&]() {
+        const bool was = st == WALK;
+        bool in = was;
+        uint32_t steps = 10u;
+        const uint32_t d0 = rng.d;
+        iterate_rot(RngHead<0>{}, RngHead<0>{}, in, steps, d0);
+        iterate_rot(RngHead<2>{}, RngHead<1>{}, in, steps, d0);
+        iterate_rot(RngHead<4>{}, RngHead<2>{}, in, steps, d0);
+        iterate_rot(RngHead<1>{}, RngHead<3>{}, in, steps, d0);
+        iterate_rot(RngHead<3>{}, RngHead<4>{}, in, steps, d0);
+        if (was) {
+            rng.d = d0 + steps * RNG_WEYL;
+            rng_canon(rng, steps >= 10u ? 0u : (steps >= 5u ? steps - 5u : steps));
         }
     };
     // the same iteration for a lane that is before its first possibly-occupied cell (t < t_occ), without the rest: the lane
@@ -360,6 +410,7 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
         begin_walk(true, k + 1u < traceDepth);
     };
 
+    const bool trips = s.trips != 0u;                  // (SVR_OPT_TRIPS)
     const uint32_t park_cheap = s.park_cheap;          // (SVR_OPT_PARK_CHEAP; SVR_PARK_CHEAP = 16 is the default)
     if constexpr (DEPTH1) {
         // traceDepth 1: the machine only walks -- pop a shaded event, shadow walk, radiance -- so its rounds are cheap
@@ -374,7 +425,10 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
                     for (uint32_t rounds = 0u; rounds < SVR_FREE_ROUNDS && (uint32_t)__popcll(__ballot(st == WALK && t < t_occ)) >= SVR_FREE_MIN_D1; ++rounds)
                         if (st == WALK && t < t_occ) free_iterate();
                 }
-                if (st == WALK || st == CELL) iterate();
+                if (POOL && trips) {
+                    if (st == CELL) iterate();
+                    trip();
+                } else if (st == WALK || st == CELL) iterate();
                 serve_fetch_march();
             }
             PROF_END(pw, 32u);
@@ -398,11 +452,16 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
                 }
                 const uint64_t mh = __ballot(to_hit);
                 if (to_hit) {
-                    uint32_t* h = queue_h(Q) + *nH + lane_rank(mh);
-                    rec_v3_store(h, Q.cap, orig + dir * t); rec_v3_store(h + 3 * Q.cap, Q.cap, -dir);
-                    h[6 * Q.cap] = f2u(val);
-                    rec_rng_store(h + 7 * Q.cap, Q.cap, rng);
-                    h[13 * Q.cap] = id;
+                    if constexpr (HIT_B) {
+                        // deeper paths: the collision is a B record of the machine that follows (first scatter event, unshaded)
+                        rec_b_store(queue_b(Q) + *nH + lane_rank(mh), Q.cap, orig + dir * t, -dir, val, V3(0.f, 0.f, 0.f), V3(1.f, 1.f, 1.f), rng, rec_meta(id, 0u, 0u, 0));
+                    } else {
+                        uint32_t* h = queue_h(Q) + *nH + lane_rank(mh);
+                        rec_v3_store(h, Q.cap, orig + dir * t); rec_v3_store(h + 3 * Q.cap, Q.cap, -dir);
+                        h[6 * Q.cap] = f2u(val);
+                        rec_rng_store(h + 7 * Q.cap, Q.cap, rng);
+                        h[13 * Q.cap] = id;
+                    }
                     st = IDLE;
                 }
                 *nH += (uint32_t)__popcll(mh);
@@ -548,7 +607,10 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
                     for (uint32_t rounds = 0u; rounds < SVR_FREE_ROUNDS && (uint32_t)__popcll(__ballot(st == WALK && t < t_occ)) >= SVR_FREE_MIN; ++rounds)
                         if (st == WALK && t < t_occ) free_iterate();
                 }
-                if (st == WALK || st == CELL) iterate();
+                if (trips) {
+                    if (st == CELL) iterate();
+                    trip();
+                } else if (st == WALK || st == CELL) iterate();
                 serve_fetch_march();
             }
 #if SVR_PROF

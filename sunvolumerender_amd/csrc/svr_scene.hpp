@@ -52,6 +52,7 @@ struct DevScene {
     uint32_t has_empty;            // 0: not one macro-cell is `empty` (media without exactly transparent space): the walks skip the mask look-ups
     uint32_t bound_cull;           // 1: the bound-class table behind the masks is valid (majorant-bound fetch culling)
     uint32_t park_end;             // lane machine: lanes waiting for shading / a walk's end / a new record before the wave serves them
+    uint32_t trips;                // lane machine: walking lanes run five iterations per turn with the generator as a circular buffer (svr_lanes.hpp)
     uint32_t park_cheap;           // lane machine at traceDepth 1: ended walks + idle lanes with a record waiting before the wave serves them
     uint32_t lm_tune;              // local-majorant pool (svr_trace_lm.hip): cells per turn | idle lanes before a refill << 8 | ended walks before they are settled << 16
     float mc_scale[3];             // macro-grid coordinate = (p - vmin) * mc_scale + mc_off

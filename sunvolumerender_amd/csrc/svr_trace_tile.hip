@@ -259,7 +259,7 @@ struct LdsPendQueue {                              // QUEUE builds: only the tas
 template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, bool QUEUE, bool POOL = false>
 __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_trace_tile(const DevScene s, const DevWork w)
 {
-    static_assert(!POOL || (QUEUE && DEPTH1 && SKIP), "the pool form exists for traceDepth 1 with the queue machine");
+    static_assert(!POOL || (QUEUE && SKIP), "the pool form exists for skipping builds with the queue machine");
     using LDS = typename std::conditional<SKIP, LdsTileCull, LdsTileNoMask>::type;
     __shared__ LDS lds;
     __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
@@ -298,7 +298,15 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
         if constexpr (QUEUE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // records and radiance are read back by other lanes of this wave
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if constexpr (POOL) {
+            if constexpr (POOL && !DEPTH1) {
+                // deeper paths: qC camera rays (P records) -> collisions = B records (first scatter events, unshaded) of the machine below
+                static_assert(REC_C1_WORDS <= REC_A_WORDS, "P records lie in front of the B stack");
+                uint32_t nH = 0u;
+                drain_queue<LAYOUT, COUNT, SKIP, true, LDS, true, true>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                qC = 0u; qA = 0u; qB = nH;
+            } else if constexpr (POOL) {
                 // qC camera rays (P records) -> collisions (H records) -> shaded, 64 at a time -> C1 records -> their shadow walks
                 uint32_t nH = 0u;
                 drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, true>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH);
@@ -552,8 +560,9 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
     const bool queue = LAYOUT != LAYOUT_LINEAR && w.fold && w.queue != nullptr && w.pend != nullptr && blocks <= w.queue_blocks && w.traceDepth < 32768u;   // a record's bounce counter has 15 bits
 #define SVR_LAUNCH_TILE(SK, D1, QU) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, SK, D1, QU>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2)
     if constexpr (LAYOUT != LAYOUT_LINEAR) {
-        if (queue && skip && d1 && cfg.pool_primary) {
-            hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, true, true, true, true>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2);
+        if (queue && skip && cfg.pool_primary) {
+            if (d1) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, true, true, true, true>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2);
+            else hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, true, false, true, true>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2);
             return hipGetLastError();
         }
         if (queue) {

@@ -377,6 +377,30 @@ def test_pooled_primary_walks_bit_exact(hip_dev, name):
     hip_dev.set_option(abi.OPT_POOL, 1)
 
 
+@pytest.mark.parametrize("name,depth", [("tiny_head", 1), ("tiny_head_noisy", 1), ("small_head_noisy", 1), ("tiny_head", 3), ("tiny_head_noisy", 2), ("small_head", 2), ("odd", 1), ("odd", 3)])
+def test_five_iteration_trips_bit_exact(hip_dev, name, depth):
+    """SVR_OPT_TRIPS: the walking lanes of the lane machine run five Woodcock iterations per turn with the generator as a circular
+    buffer (compile-time heads, one barrel rotation behind the trip); lanes that need a fetch, a re-march or are through wait for
+    the end of the trip.  Every path executes the operations of the plain machine in the same order: forced on (2; with the primary
+    walks pooled at depth 1) and off (0), the oracle's image and counters, production and counting builds, 40- and 64-frame calls."""
+    sc = _odd_scene(depth=depth) if name == "odd" else scenes.make_scene(name, trace_depth=depth)
+    try:
+        for nframes in (40, 64):
+            ref_hdr, ref_img, ref_c = oracle_frames(sc, nframes)
+            for trips in (2, 0):
+                hip_dev.set_option(abi.OPT_TRIPS, trips)
+                hip_dev.set_option(abi.OPT_POOL, 2)
+                hip_dev.set_option(abi.OPT_QUEUE, 2)
+                hdr, img, c = hip_frames(hip_dev, sc, nframes, batch=True)
+                assert_bit_exact(hdr, ref_hdr, f"{name} depth {depth}: trips = {trips}, {nframes} frames")
+                assert np.array_equal(img, ref_img)
+                assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"] and c["scatter_events"] == ref_c["scatter_events"]
+    finally:
+        hip_dev.set_option(abi.OPT_TRIPS, 1)
+        hip_dev.set_option(abi.OPT_POOL, 1)
+        hip_dev.set_option(abi.OPT_QUEUE, 1)
+
+
 def test_pinhole_camera_fast_path(hip_dev):
     """With apeture == 0 (the reference's default) the lens sample is (+-0, +-0) and camera_ray skips its square root and sine / cosine
     (SVR_OPT_PINHOLE_FAST): the oracle's image bit for bit with the switch on and off, with a camera position that holds a -0 component
