@@ -533,12 +533,13 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
     s.bound_cull = (g.opt_bound_cull == 2 || (g.opt_bound_cull == 1 && g.mask_cull_useful)) ? 1u : 0u;
     s.park_end = (uint32_t)g.opt_park_end;
     s.park_cheap = (uint32_t)g.opt_park_cheap;
-    // walks of tens of iterations with few fetches: media without exactly transparent space under bound culling (c3n: +18 %)
-    s.trips = (g.opt_trips == 2 || (g.opt_trips == 1 && s.bound_cull && !s.has_empty)) ? 1u : 0u;
     // pool tuning (same-box sweeps, gpurun_out/r03p_lm_tune.log): on the full-resolution grid (scenes with empty space) one cell per turn
     // (c3 9 920 / c5 8 430 Msamples/s against 9 480 / 7 630 with three), on the half-resolution grid of fog-like media three cells
     // and later refills (c3n 4 860 against 4 290 with one cell)
     s.lm_tune = g.opt_lm_tune ? (uint32_t)g.opt_lm_tune : (g.mask_has_empty ? (1u | (16u << 8) | (16u << 16)) : (3u | (24u << 8) | (24u << 16)));
+    // five-iteration trips of the lane machine: walks of tens of iterations with few fetches -- media without exactly transparent space under
+    // bound culling (c3n: +20 %; c3 / c5 at depth 2: -1..2 %)
+    s.trips = (g.opt_trips == 2 || (g.opt_trips == 1 && s.bound_cull && !s.has_empty)) ? 1u : 0u;
     return 0;
 }
 

@@ -52,7 +52,6 @@ struct DevScene {
     uint32_t has_empty;            // 0: not one macro-cell is `empty` (media without exactly transparent space): the walks skip the mask look-ups
     uint32_t bound_cull;           // 1: the bound-class table behind the masks is valid (majorant-bound fetch culling)
     uint32_t park_end;             // lane machine: lanes waiting for shading / a walk's end / a new record before the wave serves them
-    uint32_t trips;                // lane machine: walking lanes run five iterations per turn with the generator as a circular buffer (svr_lanes.hpp)
     uint32_t park_cheap;           // lane machine at traceDepth 1: ended walks + idle lanes with a record waiting before the wave serves them
     uint32_t lm_tune;              // local-majorant pool (svr_trace_lm.hip): cells per turn | idle lanes before a refill << 8 | ended walks before they are settled << 16
     float mc_scale[3];             // macro-grid coordinate = (p - vmin) * mc_scale + mc_off
@@ -81,6 +80,8 @@ struct DevScene {
     uint32_t num_lights;
     uint32_t primary_light_mask;   // bit i: a camera ray can reach light i (host-side conservative frustum test); the others are skipped in the nearest-light test
     DevLight lights[8];
+    uint32_t trips;                // lane machine of the tile kernel (svr_lanes.hpp): walking lanes run five iterations per turn (SVR_OPT_TRIPS).  LAST, so that the layout
+                                   // of everything else -- and with it the code of every kernel that does not read it -- stays what it was
 };
 
 // per-launch work description.  Tracing and accumulation are decoupled: the trace kernel writes the
