@@ -264,7 +264,7 @@ int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_loc
                                      * settles / refills them (1..64, default 16).  Speed only */
 #define SVR_OPT_PINHOLE_FAST 28     /* 1 (default): with apeture == 0 (the reference's default) the camera ray skips the square root and the sine / cosine of
                                      * the lens sample, which is (+-0, +-0) and provably changes no bit of the ray; the draws are consumed.  Results unchanged */
-#define SVR_OPT_POOL 29             /* tile kernel at traceDepth 1 with the queue machine: the primary walks are pooled too (a task only generates its camera
+#define SVR_OPT_POOL 29             /* tile kernel with the queue machine: the primary walks are pooled too (a task only generates its camera
                                      * rays; the lane machine walks them, the collisions are shaded 64 at a time).  0 off, 1 (default) for media without
                                      * exactly transparent space (their walks are not coherent within a wave), 2 always.  Results unchanged */
 #define SVR_OPT_TRIPS 30            /* lane machine of the tile kernel (pooled walks at traceDepth 1, every walk of deeper paths): the walking lanes run FIVE
