@@ -172,8 +172,9 @@ def test_c3_queue_machine_equals_straight_line_full_frame(c3, hip_dev):
 
 
 def test_c3n_culling_and_queue_equal_plain_walks_full_frame(hip_dev):
-    """c3 with noisy non-zero air (the bench's second workload): majorant-bound culling and the queue machine (both on by
-    default there) against the same kernel with both off, whole frame, one 64-frame launch; a window against the oracle."""
+    """c3 with noisy non-zero air (the bench's second workload): majorant-bound culling and the queue machine -- with the primary
+    walks pooled and the five-iteration trips (SVR_OPT_POOL / SVR_OPT_TRIPS: all on by default there) -- against the same kernel with
+    culling and the machine off, whole frame, one 64-frame launch; a window against the oracle."""
     r = Rig(hip_dev, "c3n")
     try:
         a, ai, _ = r.run(64)
@@ -189,7 +190,7 @@ def test_c3n_culling_and_queue_equal_plain_walks_full_frame(hip_dev):
             o.render_pathtracer(ref, f, window=w, count=False, nthreads=THREADS)
         x0, y0, x1, y1 = w
         assert_bit_exact(a[y0:y1, x0:x1], ref[y0:y1, x0:x1], "c3n vs oracle")
-        # deeper paths through this medium are queued at their first scatter event, unshaded (svr_trace_tile.hip): depth 3,
+        # deeper paths through this medium: pooled primary walks, first scatter events queued unshaded (svr_trace_tile.hip): depth 3,
         # 16-frame launch, defaults against plain walks on the whole frame, and a window against the oracle
         hip_dev.set_option(abi.OPT_QUEUE, 1)
         hip_dev.set_option(abi.OPT_BOUND_CULL, 1)
