@@ -9,8 +9,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-count --no-extra --steps ${PROF_STEPS:-2} --warmup 1 $*"
-echo "== trace" 
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; }
+echo "== trace"
+# (the kernel-trace pass is cheap: TRACE_STEPS timed steps after 2 warm-up steps, so that the average duration is not that of a cold launch)
+TRACE="python3 $ROOT/bench.py --cpu-seconds 0 --no-count --no-extra --steps ${TRACE_STEPS:-8} --warmup 2 $*"
+rm -rf $OUT/trace
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $TRACE > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; }
 i=0
 while read -r group; do
   [ -z "$group" ] && continue
