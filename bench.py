@@ -464,7 +464,10 @@ def main():
                          dict(tag=f"c3_depth{d}_local_majorant", scene="c3", depth=d, lm=1, what=f"the headline scene at trace depth {d} " + LM_WHAT)]
         plan += [dict(tag="c3_noisy_air", scene="c3n", what="c3 with noisy non-zero air (64..191 raw LSB, like CT data rescaled to the full u16 range): no "
                                                             "macro-cell is exactly transparent"),
-                 dict(tag="c3n_local_majorant", scene="c3n", lm=1, what="c3 with noisy non-zero air " + LM_WHAT),
+                 dict(tag="c3n_local_majorant", scene="c3n", lm=1, what="c3 with noisy non-zero air " + LM_WHAT)]
+        if d0 == 1 and not args.fast_math:
+            plan += [dict(tag="c3n_depth4", scene="c3n", depth=4, what="c3 with noisy non-zero air at trace depth 4, default mode")]
+        plan += [
                  dict(tag="c5", scene="c5", what="BASELINE config 5 on one GPU: 1024^3 u16 volume (HBM-resident), 1024^2, default mode"),
                  dict(tag="c5_local_majorant", scene="c5", lm=1, what="BASELINE config 5 on one GPU (1024^3 u16, 1024^2) " + LM_WHAT)]
         w2, w2_scene = wl, args.scene
