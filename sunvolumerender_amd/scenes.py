@@ -275,6 +275,8 @@ def make_scene(name: str, **overrides) -> Scene:
         "c5": ("head", 1024, 1024, 1024, 3, True, True, 512, "default"),
         # c3 / tiny_head with noisy, non-zero air: nothing is exactly transparent (see make_ct_head_volume)
         "c3n": ("head_noisy", 512, 1024, 1024, 3, True, True, 256, "default"),
+        # c3 under the bone transfer function: exactly transparent air AND translucent tissue (bound classes between 0 and 1)
+        "c3b": ("head", 512, 1024, 1024, 3, True, True, 256, "bone"),
         "tiny_head_noisy": ("head_noisy", 48, 96, 80, 3, True, True, 1, "default"),
         "small_head_noisy": ("head_noisy", 128, 256, 256, 3, True, True, 1, "default"),
         "tiny": ("sphere", 32, 64, 64, 1, False, False, 1, "default"),

@@ -218,6 +218,48 @@ def test_c3n_culling_and_queue_equal_plain_walks_full_frame(hip_dev):
 # ------------------------------------------------------------------------------------------------------------
 # c4: 512^3 volume, 2048^2 image (BASELINE config 3; tiled across 8 GPUs there)
 # ------------------------------------------------------------------------------------------------------------
+def test_c3_bone_transfer_function_vs_oracle(hip_dev):
+    """c3 under the bone transfer function (c3b): exactly transparent air AND translucent tissue -- skipping, bound classes between 0 and
+    1 and the queue machine all at work in one scene.  64-frame launch, full frame: defaults == culling and machine off; a window through
+    the skull against the oracle with counters; depth 3, 16 frames: defaults == plain walks and a window against the oracle."""
+    r = Rig(hip_dev, "c3b")
+    try:
+        a, ai, _ = r.run(64)
+        assert a.max() > 0
+        hip_dev.set_option(abi.OPT_QUEUE, 0)
+        hip_dev.set_option(abi.OPT_BOUND_CULL, 0)
+        b, bi, _ = r.run(64)
+        hip_dev.set_option(abi.OPT_QUEUE, 1)
+        hip_dev.set_option(abi.OPT_BOUND_CULL, 1)
+        assert_bit_exact(a, b, "c3b: defaults vs plain walks, full frame")
+        assert np.array_equal(ai, bi)
+        w = (480, 400, 544, 408)
+        ref, _, ref_c = _oracle_windows(r.sc, [w], 64, count=True)
+        x0, y0, x1, y1 = w
+        assert_bit_exact(a[y0:y1, x0:x1], ref[y0:y1, x0:x1], "c3b vs oracle")
+        _, _, c = r.run(64, count=True, window=w)
+        for k in ("paths", "vol_taps", "woodcock_iters", "scatter_events"):
+            assert c[k] == ref_c[k], (k, c[k], ref_c[k])
+        r.canvas.SetScatterTimes(3)
+        sc3 = dataclasses.replace(r.sc, trace_depth=3)
+        a3, _, _ = r.run(16)
+        hip_dev.set_option(abi.OPT_QUEUE, 0)
+        hip_dev.set_option(abi.OPT_BOUND_CULL, 0)
+        b3, _, _ = r.run(16)
+        assert_bit_exact(a3, b3, "c3b depth 3: defaults vs plain walks, full frame")
+        o3 = binding.OracleScene(sc3)
+        ref3 = o3.new_hdr()
+        w3 = (496, 402, 528, 406)
+        for f in range(16):
+            o3.render_pathtracer(ref3, f, window=w3, count=False, nthreads=THREADS)
+        x0, y0, x1, y1 = w3
+        assert_bit_exact(a3[y0:y1, x0:x1], ref3[y0:y1, x0:x1], "c3b depth 3 vs oracle")
+    finally:
+        hip_dev.set_option(abi.OPT_QUEUE, 1)
+        hip_dev.set_option(abi.OPT_BOUND_CULL, 1)
+        r.close()
+
+
 @pytest.fixture(scope="module")
 def c4(hip_dev):
     r = Rig(hip_dev, "c4")

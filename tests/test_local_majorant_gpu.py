@@ -14,8 +14,8 @@ The per-pixel L2 is taken on the IMAGE, i.e. after the reference's exposure curv
 L2 on raw radiance and make the ratio of two such L2s a coin toss -- count as the saturated pixels they are; where the
 radiance itself is light-tailed (trace depth 1) the same inequalities are ALSO required on the raw HDR values.
 The means are compared on the raw HDR values always; their standard error is rmse_channel(A, B) / sqrt(pixels).
-On c2 (256^3, depth 2), c3n (noisy non-zero air: nothing is exactly transparent; depth 1 and 4) and c5 (1024^3), full
-frames; and against the ORACLE's own 256-spp image on a window (the unbiasedness check does not rest on the HIP default
+On c2 (256^3, depth 2), c3n (noisy non-zero air: nothing is exactly transparent; depth 1 and 4), c5 (1024^3) and c3b (c3
+under the bone transfer function: transparent air and translucent tissue, depth 2), full frames; and against the ORACLE's own 256-spp image on a window (the unbiasedness check does not rest on the HIP default
 mode alone).
 Inside the mode a frame's radiance is still a pure function of (scene, pixel, frame): per-frame calls, batches, row
 shards and the counting build agree bit for bit.  The default mode is untouched by the switch."""
@@ -95,7 +95,7 @@ def _check_converged(A, B, F, what, hdr_l2=True):
     assert np.all(np.abs(mF - mA) <= np.maximum(3e-3 * mA, 4.0 * se)), (what, mA, mF, se)
 
 
-@pytest.mark.parametrize("name,depth,spp", [("c2", 2, 256), ("c3n", 1, 128), ("c3n", 4, 64), ("c5", 1, 128)])
+@pytest.mark.parametrize("name,depth,spp", [("c2", 2, 256), ("c3n", 1, 128), ("c3n", 4, 64), ("c5", 1, 128), ("c3b", 2, 128)])
 def test_local_majorant_converged_image_within_noise(hip_dev, name, depth, spp):
     sc, canvas = _canvas(hip_dev, name, trace_depth=depth)
     try:
