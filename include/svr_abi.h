@@ -149,9 +149,12 @@ void svr_clear_error(void);
 #define SVR_LAYOUT_LINEAR 1          /* [z][y][x] with a 2-voxel zero apron */
 #define SVR_LAYOUT_BRICK 2           /* 8x4x4-voxel bricks (256 B), 2-voxel zero apron */
 #define SVR_LAYOUT_PAIR 3            /* the same bricks with 32-bit elements: voxel x | voxel x+1 << 16 (half the gather instructions per
-                                        trilinear fetch, twice the memory); volumes up to ~1000^3; what AUTO picks when it fits */
-#define SVR_LAYOUT_CELL 4            /* the same bricks with 16-byte elements: the 8 voxels of a trilinear cell -- one 16-byte load per fetch, one 32-byte
-                                     * sector instead of four; 8 x the memory of the u16 volume (2.2 GB for 512^3), volumes up to ~640^3 (32-bit offsets) */
+                                        trilinear fetch, twice the memory; 32-bit byte offsets: volumes up to ~1000^3); what AUTO falls back to
+                                        when CELL does not fit the addressing limits or the device memory */
+#define SVR_LAYOUT_CELL 4            /* the same bricks with 16-byte elements: the 8 voxels of a trilinear cell -- one 16-byte load per fetch, one
+                                     * sector instead of four; 8 x the memory of the u16 volume (2.2 GB for 512^3, 17 GB for 1024^3); 32-bit element
+                                     * index, 64-bit byte offsets.  What AUTO picks FIRST (then PAIR, then BRICK, then LINEAR: the next one when
+                                     * the addressing limits or hipErrorOutOfMemory rule one out; csrc/svr_api.hip, create_volume_texture) */
 uint64_t svr_create_volume_texture(const uint16_t* voxels, int nx, int ny, int nz,
                                    int src_is_device, int layout);
 /* gui/transferfunction.cpp:30-44 (1D float4 array, clamp / linear / normalized coords). */
@@ -270,6 +273,13 @@ int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_loc
 #define SVR_OPT_TRIPS 30            /* lane machine of the tile kernel (pooled walks at traceDepth 1, every walk of deeper paths): the walking lanes run FIVE
                                      * Woodcock iterations per turn with the generator as a circular buffer (no register moves), a lane that needs a fetch waits
                                      * for the end of the trip.  0 off, 1 (default) for media without exactly transparent space, 2 always.  Results unchanged */
+#define SVR_OPT_NAN_GUARD 31        /* OPT-IN, default 0 = the reference's behaviour: running_estimate (pathtracer.cu:81-84,279) keeps a NaN for good, and the
+                                     * reference's own arithmetic yields one (0/0 in the microfacet term, pathtracer.cu:106-131, core/bsdf/microfacet.h:52-68) for a
+                                     * handful of paths in 10^8..10^9 -- a permanently dead pixel.  1: a non-finite sample (per channel) is replaced by the running mean
+                                     * before it is folded in, i.e. dropped.  Every other sample and pixel keeps its bits */
+#define SVR_OPT_MACRO_SHIFT_MIN 32  /* volume textures created from now on get macro-cells of at least 2^v voxels per axis (0..6; default 0 = the smallest cells
+                                     * whose grid fits 64^3).  Coarser acceleration data; the default mode's results are unchanged (bit-exact), the local-majorant
+                                     * mode's estimate changes with its grid.  For tests of the coarse-grid code paths on small volumes */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */

@@ -121,7 +121,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1, opt_nan_guard = 0, opt_macro_shift_min = 0;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -392,6 +392,7 @@ int fill_work(svr::DevWork& w, uint32_t W, uint32_t H)
     w.refill_min_idle = (uint32_t)g.opt_refill;
     w.debug_stop = (uint32_t)g.opt_debug_stop;
     w.row_order = (uint32_t)g.opt_row_order;
+    w.nan_guard = (uint32_t)g.opt_nan_guard;
     w.strip_rows = g.strip_rows ? g.strip_rows : 1;
     w.rank = g.rank;
     w.world = g.world;
@@ -974,7 +975,7 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
     if (elems >= ((size_t)1 << 32) || (layout != SVR_LAYOUT_CELL && elems >= ((size_t)1 << 31))) { delete t; fail(-6, "svr_create_volume_texture: %zu padded voxels exceed 32-bit byte offsets", elems); return 0; }
     // macro-cell grid for empty-space skipping: smallest cell size whose bitmask fits MASK_WORDS_MAX words
     {
-        int sh = 0;
+        int sh = g.opt_macro_shift_min;                       // (SVR_OPT_MACRO_SHIFT_MIN: coarser cells on request)
         for (;; ++sh) {
             size_t gx = (((size_t)nx - 1) >> sh) + 1, gy = (((size_t)ny - 1) >> sh) + 1, gz = (((size_t)nz - 1) >> sh) + 1;
             if (gx * gy * gz <= (size_t)svr::MASK_WORDS_MAX * 32) { t->mc_shift = sh; t->mc_gx = (int)gx; t->mc_gy = (int)gy; t->mc_gz = (int)gz; break; }
@@ -1426,6 +1427,10 @@ int svr_set_option(int key, int value)
     case SVR_OPT_PARK_END:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_END: bad value %d (1..64)", value);
         g.opt_park_end = value; return 0;
+    case SVR_OPT_NAN_GUARD: g.opt_nan_guard = value ? 1 : 0; return 0;
+    case SVR_OPT_MACRO_SHIFT_MIN:
+        if (value < 0 || value > 6) return fail(-6, "SVR_OPT_MACRO_SHIFT_MIN: bad value %d (0..6)", value);
+        g.opt_macro_shift_min = value; return 0;
 #ifdef SVR_TEST_HOOKS
     // experiment builds only (tools/exp.py; `SVR_EXTRA_HIPCC_FLAGS=-DSVR_TEST_HOOKS python -m sunvolumerender_amd._build --force`)
     case 100: g.opt_debug_stop = value; return 0;      // timing ablation: stop every path after a phase (wrong images)
@@ -1473,6 +1478,8 @@ int svr_get_option(int key)
     case SVR_OPT_PINHOLE_FAST: return g.opt_pinhole_fast;
     case SVR_OPT_POOL: return g.opt_pool;
     case SVR_OPT_TRIPS: return g.opt_trips;
+    case SVR_OPT_NAN_GUARD: return g.opt_nan_guard;
+    case SVR_OPT_MACRO_SHIFT_MIN: return g.opt_macro_shift_min;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;
     case SVR_OPT_FRAMES_PER_WAVE_LOG2: return g.opt_frames_log2;
     case SVR_OPT_RAYCAST_LANES_LOG2: return g.opt_rc_lanes;

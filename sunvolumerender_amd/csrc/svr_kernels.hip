@@ -435,6 +435,11 @@ __global__ __launch_bounds__(256) void k_resolve(const DevScene s, const DevWork
     for (uint32_t f = 0; f < w.nframes; ++f) {
         const float* l = w.lbuf + (size_t)f * w.slot_stride + 3 * off;
         v3 L = V3(l[0], l[1], l[2]);
+        if (w.nan_guard) {                                  // SVR_OPT_NAN_GUARD: a non-finite sample is replaced by the running mean (per channel)
+            L.x = (f2u(L.x) & 0x7f800000u) == 0x7f800000u ? acc.x : L.x;
+            L.y = (f2u(L.y) & 0x7f800000u) == 0x7f800000u ? acc.y : L.y;
+            L.z = (f2u(L.z) & 0x7f800000u) == 0x7f800000u ? acc.z : L.z;
+        }
         float n1 = (float)(w.frame0 + f) + 1.f;
         acc = acc + (L - acc) / n1;
     }

@@ -112,6 +112,7 @@ struct DevWork {
     uint32_t* queue;               // tile kernel, QUEUE builds: scatter-record queues, REC_WORDS * QUEUE_CAP words per wave; null = straight-line paths
     float* pend;                   // ... and the waves' pending-radiance rows, QUEUE_TASKS * 3 * 64 floats per wave
     uint32_t queue_blocks;         // blocks the queue memory is sized for
+    uint32_t nan_guard;            // SVR_OPT_NAN_GUARD: the running mean skips non-finite samples (default 0 = the reference's behaviour)
 };
 
 } // namespace svr

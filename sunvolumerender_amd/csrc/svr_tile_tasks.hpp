@@ -56,10 +56,20 @@ SVR_DEV void fold_pending(const DevScene& s, const DevWork& w, const float* rows
         float* h = w.hdr + 3 * ((size_t)y * s.imageW + x) + ch;
         float acc = (w.frame0 == 0u) ? 0.f : *h;
         const float* rp = rows + (size_t)(q * 3u + ch) * row + pl;
-        for (uint32_t f = 0; f < nfr; ++f) {
-            const float Lf = rp[f << ts.P2];
-            const float n1 = (float)(w.frame0 + f) + 1.f;
-            acc = acc + (Lf - acc) / n1;
+        if (w.nan_guard) {
+            // SVR_OPT_NAN_GUARD: a non-finite sample (the reference's 0/0, pathtracer.cu:106-131) is replaced by the running mean
+            for (uint32_t f = 0; f < nfr; ++f) {
+                float Lf = rp[f << ts.P2];
+                Lf = (f2u(Lf) & 0x7f800000u) == 0x7f800000u ? acc : Lf;
+                const float n1 = (float)(w.frame0 + f) + 1.f;
+                acc = acc + (Lf - acc) / n1;
+            }
+        } else {
+            for (uint32_t f = 0; f < nfr; ++f) {
+                const float Lf = rp[f << ts.P2];
+                const float n1 = (float)(w.frame0 + f) + 1.f;
+                acc = acc + (Lf - acc) / n1;
+            }
         }
         *h = acc;
     }

@@ -38,16 +38,25 @@ def _make(name, **kw):
     return scenes.make_scene(name, **kw)
 
 
-def _canvas(dev, name, **kw):
+def _canvas(dev, name, macro_shift_min=0, **kw):
+    """macro_shift_min: SVR_OPT_MACRO_SHIFT_MIN while the volume texture is created -- macro-cells of at least 2^v voxels, so that the
+    coarse-grid code of the mode (sub-cell occupancy needs cells of >= 2 voxels; by default only volumes beyond 512^3 have it on) runs on
+    the small scenes whose means can be resolved to 0.05 %"""
     sc = _make(name, **kw)
     canvas = host.Canvas(dev, sc.width, sc.height)
-    scenes.apply_to_canvas(sc, canvas)
+    dev.set_option(abi.OPT_MACRO_SHIFT_MIN, macro_shift_min)
+    try:
+        scenes.apply_to_canvas(sc, canvas)
+    finally:
+        dev.set_option(abi.OPT_MACRO_SHIFT_MIN, 0)
     return sc, canvas
 
 
-def _render(dev, canvas, lm, frames):
-    """progressive render; returns the accumulator after each entry of `frames` (cumulative calls)"""
+def _render(dev, canvas, lm, frames, sub=1):
+    """progressive render; returns the accumulator after each entry of `frames` (cumulative calls).  sub = SVR_OPT_LM_SUBCELLS
+    (0 off, 1 where macro-cells are >= 16 voxels, 2 wherever a fine level exists): part of the mode's definition"""
     dev.set_option(abi.OPT_LOCAL_MAJORANT, 1 if lm else 0)
+    dev.set_option(abi.OPT_LM_SUBCELLS, sub)
     canvas.ReStartRender()
     out = []
     for n in frames:
@@ -55,6 +64,7 @@ def _render(dev, canvas, lm, frames):
         dev.synchronize()
         out.append(canvas.read_hdr().astype(np.float64))
     dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
+    dev.set_option(abi.OPT_LM_SUBCELLS, 1)
     return out
 
 
@@ -95,14 +105,19 @@ def _check_converged(A, B, F, what, hdr_l2=True):
     assert np.all(np.abs(mF - mA) <= np.maximum(3e-3 * mA, 4.0 * se)), (what, mA, mF, se)
 
 
-@pytest.mark.parametrize("name,depth,spp", [("c2", 2, 256), ("c3n", 1, 128), ("c3n", 4, 64), ("c5", 1, 128), ("c3b", 2, 128)])
-def test_local_majorant_converged_image_within_noise(hip_dev, name, depth, spp):
+@pytest.mark.parametrize("name,depth,spp,sub", [("c2", 2, 256, 1), ("c3n", 1, 128, 1), ("c3n", 4, 64, 1), ("c5", 1, 128, 1), ("c5", 1, 128, 0), ("c3b", 2, 128, 1), ("c3", 1, 128, 2)])
+def test_local_majorant_converged_image_within_noise(hip_dev, name, depth, spp, sub):
+    """sub: SVR_OPT_LM_SUBCELLS -- c5 (16-voxel macro-cells) has the sub-cell occupancy on by default and is also rendered without it,
+    c3 (8-voxel cells) has it off by default and is also rendered with it forced on"""
     sc, canvas = _canvas(hip_dev, name, trace_depth=depth)
     try:
         A, A2 = _render(hip_dev, canvas, False, (spp, spp))
         B = 2.0 * A2 - A
-        (F,) = _render(hip_dev, canvas, True, (spp,))
-        _check_converged(A, B, F, f"{name} depth {depth}", hdr_l2=depth <= 1)
+        (F,) = _render(hip_dev, canvas, True, (spp,), sub=sub)
+        _check_converged(A, B, F, f"{name} depth {depth} sub-cells {sub}", hdr_l2=depth <= 1)
+        if sub != 1:
+            (F1,) = _render(hip_dev, canvas, True, (spp,))
+            assert not np.array_equal(F1, F), "SVR_OPT_LM_SUBCELLS changed nothing: did the sub-cell branch run?"
         # the default mode is untouched by the switch
         (A3,) = _render(hip_dev, canvas, False, (spp,))
         assert_bit_exact(A3.astype(np.float32), A.astype(np.float32), "default mode after the local-majorant mode was used")
@@ -111,40 +126,58 @@ def test_local_majorant_converged_image_within_noise(hip_dev, name, depth, spp):
         canvas.close()
 
 
-def test_local_majorant_unbiased_against_the_oracle(hip_dev):
+_ORACLE_WINDOW = {}
+
+
+@pytest.mark.parametrize("sub", [1, 2])
+def test_local_majorant_unbiased_against_the_oracle(hip_dev, sub):
     """The same three inequalities with the ORACLE in the place of the default mode: a 96x48 window of small_head (128^3,
-    256^2, 3 lights + env, depth 2) at 256 spp; O = oracle frames 0..255, O2 = oracle frames 256..511."""
+    256^2, 3 lights + env, depth 2) at 256 spp; O = oracle frames 0..255, O2 = oracle frames 256..511.  small_head has macro-cells of
+    2 voxels: sub = 2 forces the sub-cell occupancy on (1-voxel fine cells), sub = 1 leaves it off there."""
     sc, canvas = _canvas(hip_dev, "small_head", trace_depth=2)
     try:
         N = 256
         win = (80, 100, 176, 148)
         x0, y0, x1, y1 = win
-        o = binding.OracleScene(sc)
-        acc = o.new_hdr()
-        for f in range(N):
-            o.render_pathtracer(acc, f, trace_depth=2, window=win, count=False)
-        O = acc[y0:y1, x0:x1].astype(np.float64)
-        for f in range(N, 2 * N):
-            o.render_pathtracer(acc, f, trace_depth=2, window=win, count=False)
-        O2 = 2.0 * acc[y0:y1, x0:x1].astype(np.float64) - O
-        (F,) = _render(hip_dev, canvas, True, (N,))
-        _check_converged(O, O2, F[y0:y1, x0:x1], "small_head window vs oracle", hdr_l2=False)
+        if "O" not in _ORACLE_WINDOW:                          # (the oracle's 512 frames of the window are rendered once for both settings)
+            o = binding.OracleScene(sc)
+            acc = o.new_hdr()
+            for f in range(N):
+                o.render_pathtracer(acc, f, trace_depth=2, window=win, count=False)
+            O = acc[y0:y1, x0:x1].astype(np.float64)
+            for f in range(N, 2 * N):
+                o.render_pathtracer(acc, f, trace_depth=2, window=win, count=False)
+            _ORACLE_WINDOW["O"], _ORACLE_WINDOW["O2"] = O, 2.0 * acc[y0:y1, x0:x1].astype(np.float64) - O
+        O, O2 = _ORACLE_WINDOW["O"], _ORACLE_WINDOW["O2"]
+        (F,) = _render(hip_dev, canvas, True, (N,), sub=sub)
+        _check_converged(O, O2, F[y0:y1, x0:x1], f"small_head window vs oracle, sub-cells {sub}", hdr_l2=False)
+        if sub == 2:
+            (F1,) = _render(hip_dev, canvas, True, (N,))
+            assert not np.array_equal(F1, F), "SVR_OPT_LM_SUBCELLS = 2 changed nothing on small_head: did the sub-cell branch run?"
     finally:
         hip_dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
         canvas.close()
 
 
-@pytest.mark.parametrize("name,depth", [("tiny_head", 1), ("tiny_head", 2), ("tiny_head_noisy", 1), ("tiny_bone", 2), ("odd", 1), ("odd", 3)])
-def test_local_majorant_means_agree_at_high_sample_counts(hip_dev, name, depth):
+@pytest.mark.parametrize("name,depth,shift,sub", [("tiny_head", 1, 0, 1), ("tiny_head", 2, 0, 1), ("tiny_head_noisy", 1, 0, 1), ("tiny_bone", 2, 0, 1), ("odd", 1, 0, 1), ("odd", 3, 0, 1),
+                                                  ("tiny_head", 1, 2, 2), ("tiny_head", 2, 3, 2), ("tiny_bone", 2, 2, 2), ("odd", 1, 2, 2), ("odd", 3, 1, 2), ("tiny_head", 1, 2, 0)])
+def test_local_majorant_means_agree_at_high_sample_counts(hip_dev, name, depth, shift, sub):
     """A bias of a few 0.1 % hides in the noise of 256 spp.  Small frames at 8192 spp, default mode against local-majorant mode:
     the per-channel means of the frame and of its four quadrants within 4 standard errors (estimated from two independent halves
-    of the default render), or 0.05 % where the noise is smaller than that."""
-    sc, canvas = _canvas(hip_dev, name, trace_depth=depth)
+    of the default render), or 0.05 % where the noise is smaller than that.
+    shift / sub: macro-cells of 2^shift voxels (SVR_OPT_MACRO_SHIFT_MIN) with the SUB-CELL OCCUPANCY forced on (sub = 2: the free path
+    is spent only in the occupied eighths of a macro-cell, svr_trace_lm.hip lm_step -- on by default only for volumes beyond 512^3)
+    or off (sub = 0) on the coarse grid: the branch c5's numbers rest on, held to the same test as the rest of the mode."""
+    sc, canvas = _canvas(hip_dev, name, macro_shift_min=shift, trace_depth=depth)
     try:
         N = 4096
         A, A2 = _render(hip_dev, canvas, False, (N, N))          # frames 0..N-1, then the mean of 0..2N-1
         B = 2.0 * A2 - A
-        (F2,) = _render(hip_dev, canvas, True, (2 * N,))
+        (F2,) = _render(hip_dev, canvas, True, (2 * N,), sub=sub)
+        if sub == 2:
+            (G,) = _render(hip_dev, canvas, True, (64,), sub=0)
+            (G2,) = _render(hip_dev, canvas, True, (64,), sub=2)
+            assert not np.array_equal(G, G2), "SVR_OPT_LM_SUBCELLS = 2 changed nothing: did the sub-cell branch run?"
         H, W = A.shape[:2]
         A, A2, B, F2 = _drop_reference_nans(A, A2, B, F2)
         for (y0, y1, x0, x1) in [(0, H, 0, W), (0, H // 2, 0, W // 2), (0, H // 2, W // 2, W), (H // 2, H, 0, W // 2), (H // 2, H, W // 2, W)]:

@@ -710,3 +710,34 @@ def test_baseline_configs_full_frame(hip_dev, name, frames):
     finally:
         hip_dev.set_option(abi.OPT_COUNT, 0)
         canvas.close()
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_nan_guard_drops_non_finite_samples(hip_dev, depth):
+    """The reference's running mean keeps a NaN for good (pathtracer.cu:81-84,279), and its own arithmetic yields one now and then
+    (0/0 in the microfacet term).  Here EVERY next-event estimate is NaN: a light of radius 0 has area 0, radiance = x / 0 = inf and
+    pdf = inf, so Ld = (B * kf) * inf / inf (pathtracer.cu:191-198).  Default mode: the HIP image has its NaNs exactly where the
+    oracle has them (x86 and gfx950 disagree about the sign bit of a default NaN: assert_bit_exact treats NaN = NaN) and the same
+    bits elsewhere.  SVR_OPT_NAN_GUARD = 1 (opt-in): no NaN is left, every pixel that had none keeps its bits, and the two
+    accumulation paths (one 16-frame folding launch; 16 render_pathtracer calls = frames traced ahead + k_resolve) agree."""
+    base = scenes.make_scene("tiny_head", trace_depth=depth)
+    sc = dataclasses.replace(base, lights=[host.place_area_light(20.0, 30.0, 80.0, 0.0, (1, 1, 1), 300.0)])
+    N = 16
+    ref_hdr, ref_img, _ = oracle_frames(sc, N)
+    n_nan = int(np.isnan(ref_hdr).any(axis=2).sum())
+    assert n_nan > 100, n_nan
+    hdr, img, _ = hip_frames(hip_dev, sc, N, batch=True)
+    assert_bit_exact(hdr, ref_hdr, "radius-0 light, default mode (NaNs in the same pixels)")
+    assert np.array_equal(img, ref_img)
+    hip_dev.set_option(abi.OPT_NAN_GUARD, 1)
+    try:
+        g_hdr, g_img, _ = hip_frames(hip_dev, sc, N, batch=True)
+        g2_hdr, g2_img, _ = hip_frames(hip_dev, sc, N, batch=False)
+    finally:
+        hip_dev.set_option(abi.OPT_NAN_GUARD, 0)
+    assert np.isfinite(g_hdr).all()
+    clean = ~np.isnan(ref_hdr).any(axis=2)
+    assert_bit_exact(g_hdr[clean], ref_hdr[clean], "NAN_GUARD: pixels without a NaN keep their bits")
+    assert_bit_exact(g_hdr, g2_hdr, "NAN_GUARD: folding launch vs per-frame calls")
+    assert np.array_equal(g_img, g2_img)
+    assert (g_hdr[~clean] >= 0).all()
