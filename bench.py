@@ -449,6 +449,28 @@ def main():
     # ---- secondary workloads (one GPU only) ----
     if world == 1 and not args.no_extra and args.scene == "c3" and args.kernel in (0, 2):
         extra = {}
+        # the reference's own host protocol (gui/canvas.cpp:96-116): ONE render_pathtracer call + ONE device synchronisation per frame, frameNo++ --
+        # what an unmodified host does.  Frames are traced ahead in batches (1, 2, 4 ... 64) on the library's streams and a call folds its frame;
+        # the ramp (frames 0..63) and the steady state (frames 64..1087) are timed separately, the steady state is the figure of `summary`
+        canvas.ReStartRender()
+        for _ in range(200):
+            canvas.paint(sync=True)
+        canvas.ReStartRender()
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(64):
+            canvas.paint(sync=True)
+        torch.cuda.synchronize()
+        tp1 = time.perf_counter()
+        for _ in range(1024):
+            canvas.paint(sync=True)
+        torch.cuda.synchronize()
+        tp2 = time.perf_counter()
+        extra["c3_per_frame_calls"] = {"value": round(float(W) * H * 1024 / (tp2 - tp1) / 1e6, 3), "unit": "Msamples/s", "steps": 1024, "ms_per_step": round((tp2 - tp1) / 1024 * 1e3, 4),
+                                       "trace_depth": args.trace_depth, "ramp_frames_0_63": round(float(W) * H * 64 / (tp1 - tp0) / 1e6, 3),
+                                       "what": "the headline scene under the reference's host protocol: one render_pathtracer call + one svr_device_synchronize per frame "
+                                               "(gui/canvas.cpp:96-116), frames 64..1087 of a progressive render (steady state of frame-ahead tracing; `ramp_frames_0_63` = the first 64 frames)",
+                                       "roofline": {"frac": None}}
         # (the C ABI holds ONE scene per process, like the reference's __constant__ globals: the headline canvas goes
         # first, every further canvas replaces the scene and nothing is rendered on an earlier one afterwards)
         LM_WHAT = ("in the OPT-IN local-majorant mode (SVR_OPT_LOCAL_MAJORANT, 'Woodcock max-density acceleration': delta tracking against "

@@ -89,6 +89,8 @@ struct Context {
     uint32_t queue_blocks = 0;          // blocks both are sized for
     bool queue_alloc_failed = false;    // SVR_OPT_QUEUE = 1 and the device had no room for them: straight-line launches
     hipEvent_t prev_traced = nullptr;   // `traced` event of the latest trace launch (owned by its set)
+    hipEvent_t queue_done = nullptr;    // recorded behind every launch that uses d_queue / d_pend (there is ONE such memory: its users run one after the other, on whatever stream)
+    bool queue_used = false;
     // frames traced ahead of the host's render_pathtracer calls (render_frames)
     struct Ahead {
         bool valid = false;
@@ -108,6 +110,7 @@ struct Context {
 #define SVR_GROUP 32     // frames per trace launch: 8 / 16 / 32 / 64 measured 0.185 / 0.178 / 0.166 / 0.161 ms per frame on c3
 #endif
     static constexpr int NSETS = 4, GROUP = SVR_GROUP;
+    static constexpr int AHEAD_MAX = 64;                     // frames per launch of the steady state of frame-ahead tracing (a wave = one pixel x 64 frames, like a folding launch)
     static constexpr uint64_t CHAIN_MIN_PATHS = 12u << 20;   // paths of a trace launch from which launches are chained
     struct SlotSet {
         float* lbuf = nullptr;
@@ -219,6 +222,7 @@ int ensure_init()
         HIP_TRY(hipEventCreateWithFlags(&g.sets[i].traced, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g.sets[i].resolved, hipEventDisableTiming));
     }
+    HIP_TRY(hipEventCreateWithFlags(&g.queue_done, hipEventDisableTiming));
     for (int i = 0; i < Context::EV_RING; ++i) {
         HIP_TRY(hipEventCreate(&g.ev0[i]));
         HIP_TRY(hipEventCreate(&g.ev1[i]));
@@ -668,7 +672,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     // POOL (svr_trace_tile.hip): pooled primary walks pay where the walks of a wave are not coherent -- media without exactly transparent
     // space under bound culling (c3n) -- and cost where they are (c3): auto = such media only
     cfg.pool_primary = use_queue && (g.opt_pool == 2 || (g.opt_pool == 1 && s.bound_cull && !s.has_empty));
-    if (use_queue || (local_majorant && fold_batch)) {
+    if (use_queue || (local_majorant && fold_batch)) {          // (a frame-ahead call traces its batches with the same kernels)
         bool available = true;
         if (ensure_record_queues((uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / 16u, g.opt_queue == 1 && !local_majorant, available)) return g.err_code;
         use_queue = use_queue && available;
@@ -705,7 +709,9 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
             slot = g.ev_head;
             HIP_TRY(hipEventRecord(g.ev0[slot], g.stream));
         }
+        if (w.queue != nullptr && g.queue_used) HIP_TRY(hipStreamWaitEvent(g.stream, g.queue_done, 0));
         HIP_TRY(launch_tile(w, g.stream));
+        if (w.queue != nullptr) { HIP_TRY(hipEventRecord(g.queue_done, g.stream)); g.queue_used = true; }
         if (g.opt_timing) {
             HIP_TRY(hipEventRecord(g.ev1[slot], g.stream));
             g.ev_head = (g.ev_head + 1) % Context::EV_RING;
@@ -716,7 +722,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     };
     // one trace launch of n_trace frames starting at frame `first` into scratch set `si`, then the resolve of its
     // first n_resolve frames
-    auto trace_group = [&](int si, uint32_t first, uint32_t n_trace, uint32_t n_resolve, bool want_img) -> int {
+    auto trace_group = [&](int si, uint32_t first, uint32_t n_trace, uint32_t n_resolve, bool want_img, bool with_queue = false) -> int {
         Context::SlotSet& set = g.sets[si];
         for (auto& a : g.ahead) if (a.valid && a.set == si) a.valid = false;     // its slots are about to be overwritten
         hipStream_t ts = g.opt_pipeline ? set.stream : g.stream;
@@ -730,6 +736,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         w.traceDepth = rp->traceDepth;
         w.frame0 = first;
         w.nframes = n_trace;
+        if (with_queue) { w.queue = g.d_queue; w.pend = g.d_pend; w.queue_blocks = g.queue_blocks; }
         // the scratch slots of this set are free again once their previous resolve has run
         if (g.opt_pipeline && set.used) HIP_TRY(hipStreamWaitEvent(ts, set.resolved, 0));
         // A large trace launch fills the chip by itself; running two of them at once only makes them share L2
@@ -746,8 +753,11 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         }
         if (cfg.kernel == svr::KERNEL_WAVEFRONT)
             HIP_TRY(svr::launch_wavefront(s, w, cfg, set.planes, set.wf_counts, (uint32_t)g.queue_capacity, ts));
-        else if (cfg.kernel == svr::KERNEL_TILE) HIP_TRY(launch_tile(w, ts));
-        else HIP_TRY(svr::launch_pathtrace(s, w, cfg, ts));
+        else if (cfg.kernel == svr::KERNEL_TILE) {
+            if (w.queue != nullptr && g.queue_used) HIP_TRY(hipStreamWaitEvent(ts, g.queue_done, 0));
+            HIP_TRY(launch_tile(w, ts));
+            if (w.queue != nullptr) { HIP_TRY(hipEventRecord(g.queue_done, ts)); g.queue_used = true; }
+        } else HIP_TRY(svr::launch_pathtrace(s, w, cfg, ts));
         if (g.opt_timing) {
             HIP_TRY(hipEventRecord(g.ev1[slot], ts));
             g.ev_head = (g.ev_head + 1) % Context::EV_RING;
@@ -756,7 +766,9 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         if (g.opt_pipeline) {
             HIP_TRY(hipEventRecord(set.traced, ts));
             g.prev_traced = set.traced;
-            HIP_TRY(hipStreamWaitEvent(g.stream, set.traced, 0));
+            // (a batch traced purely AHEAD -- nothing of it is resolved by this call -- must not hold the caller's stream: the calls that
+            // consume the batch in stock run beside it and wait for `traced` when they get to this one)
+            if (n_resolve) HIP_TRY(hipStreamWaitEvent(g.stream, set.traced, 0));
         }
         if (n_resolve) {
             w.nframes = n_resolve;
@@ -785,6 +797,13 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         const uint32_t n = rp->frameNo;
         svr::DevWork shape;
         fill_work(shape, s.imageW, s.imageH);
+        // at most 4 GB of scratch frames per set (64 frames up to ~2300^2 pixels; fewer for larger images)
+        const uint64_t slot_bytes = (uint64_t)3 * s.imageW * s.imageH * sizeof(float);
+        uint32_t batch_max = 1;
+        while (batch_max < (uint32_t)Context::AHEAD_MAX && 2ull * batch_max * slot_bytes <= (4ull << 30)) batch_max *= 2u;
+        // the queue builds of the tile kernel (first scatter events shaded in place, then the lane machine) for the batches too: they hand
+        // their radiance rows to the scratch slots instead of folding them (svr_tile_tasks.hpp, scatter_pending)
+        const bool ahead_queue = use_queue && !local_majorant && !g.opt_fast_math;
         auto in_stock = [&](const Context::Ahead& a, uint32_t frame) {
             return a.valid && a.content == g.content_version && a.depth == rp->traceDepth && frame >= a.first && frame - a.first < a.count &&
                    memcmp(&a.scene, &s, sizeof s) == 0 && a.shape.x0 == shape.x0 && a.shape.x1 == shape.x1 && a.shape.y0 == shape.y0 &&
@@ -805,20 +824,17 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
             HIP_TRY(hipStreamWaitEvent(g.stream, set.traced, 0));
             HIP_TRY(svr::launch_resolve(s, w, g.stream));
             HIP_TRY(hipEventRecord(set.resolved, g.stream));
-            // steady state: half-way through a full batch, start tracing the next one so that it is ready in time
+            // steady state: a full batch takes as long to trace as to consume, so the NEXT one starts when this one is first used (it runs on
+            // its set's stream beside the per-call resolves: the queue builds of the tile kernel leave the register room a resolve wave needs)
             const uint32_t next_first = a.first + a.count;
-            if (a.count == (uint32_t)Context::GROUP && n - a.first >= a.count / 2u && !in_stock(g.ahead[0], next_first) && !in_stock(g.ahead[1], next_first))
-                return trace_group(next_set(), next_first, (uint32_t)Context::GROUP, 0, false);
+            if (a.count == batch_max && !in_stock(g.ahead[0], next_first) && !in_stock(g.ahead[1], next_first))
+                return trace_group(next_set(), next_first, batch_max, 0, false, ahead_queue);
             return 0;
         }
-        // at most 2 GB of scratch frames per set (32 frames up to ~2300^2 pixels; fewer for larger images)
-        const uint64_t slot_bytes = (uint64_t)3 * s.imageW * s.imageH * sizeof(float);
-        uint32_t batch_max = 1;
-        while (batch_max < (uint32_t)Context::GROUP && 2ull * batch_max * slot_bytes <= (2ull << 30)) batch_max *= 2u;
         uint32_t batch = 1;
         while (batch < batch_max && 2u * batch <= n + 1u) batch *= 2u;
         if (batch > 1 && ensure_slots(s.imageW, s.imageH, batch_max)) return g.err_code;
-        return trace_group(next_set(), n, batch, 1, want_img);
+        return trace_group(next_set(), n, batch, 1, want_img, ahead_queue && batch >= 16u);
     }
 
     // folding launches may take 64 frames (a wave = ONE pixel x 64 frames): half as many launch boundaries
@@ -885,6 +901,7 @@ void svr_shutdown(void)
     if (g.d_ticket) hipFree(g.d_ticket);
     if (g.d_queue) hipFree(g.d_queue);
     if (g.d_pend) hipFree(g.d_pend);
+    if (g.queue_done) hipEventDestroy(g.queue_done);
     if (g_stage) { hipFree(g_stage); g_stage = nullptr; g_stage_floats = 0; }
     for (int i = 0; i < Context::EV_RING; ++i) {
         if (g.ev0[i]) hipEventDestroy(g.ev0[i]);
@@ -907,9 +924,12 @@ int svr_set_stream(void* hip_stream)
 
 int svr_device_synchronize(void)
 {
+    // canvas.cpp:106 synchronises so that the image can be shown: everything that touches the CALLER's buffers (accumulator, image, counters)
+    // runs on the launch stream or is ordered into it with events.  Frames being traced ahead on the library's own streams write only the
+    // library's scratch slots and are NOT waited for -- a host that synchronises after every render_pathtracer call (the reference's
+    // paintGL) would otherwise stall on the next batch at every batch boundary.
     if (ensure_init()) return g.err_code;
     HIP_TRY(hipStreamSynchronize(g.stream));
-    HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
 

@@ -543,9 +543,44 @@ hipError_t launch_pathtrace(const DevScene& s, const DevWork& w, const LaunchCfg
     return cfg.count ? launch_pathtrace_t<LAYOUT_BRICK, true>(s, w, cfg, st) : launch_pathtrace_t<LAYOUT_BRICK, false>(s, w, cfg, st);
 }
 
+// The resolve of ONE frame over the WHOLE image -- what a render_pathtracer call does when its frame was traced ahead (svr_api.hip) -- beside
+// a persistent trace kernel that holds every CU: the queue builds of the tile kernel leave 32 VGPRs per SIMD free, so a resolve wave is
+// resident only if it needs <= 32 registers, and then there is ONE of it per SIMD (k_resolve, 18 registers, one pixel per lane: 12 + 12
+// bytes in flight per lane, 150 us per frame measured inside a trace launch).  The running mean does not care about channels, so it runs
+// over the frame as a flat float array, 16 bytes per lane and load (k_mean_flat: <= 16 registers, two waves per SIMD), and the tone map
+// follows as k_tonemap (8 registers, four waves per SIMD).  Same float operations per value as k_resolve.
+__global__ __launch_bounds__(256) void k_mean_flat(float4* __restrict__ hdr, const float4* __restrict__ L, uint32_t n4, uint32_t frame0, uint32_t nan_guard)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n4) return;
+    const float4 l = L[i];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (frame0 != 0u) a = hdr[i];
+    float lx = l.x, ly = l.y, lz = l.z, lw = l.w;
+    if (nan_guard) {
+        lx = (f2u(lx) & 0x7f800000u) == 0x7f800000u ? a.x : lx;
+        ly = (f2u(ly) & 0x7f800000u) == 0x7f800000u ? a.y : ly;
+        lz = (f2u(lz) & 0x7f800000u) == 0x7f800000u ? a.z : lz;
+        lw = (f2u(lw) & 0x7f800000u) == 0x7f800000u ? a.w : lw;
+    }
+    const float n1 = (float)frame0 + 1.f;
+    a.x = a.x + (lx - a.x) / n1;
+    a.y = a.y + (ly - a.y) / n1;
+    a.z = a.z + (lz - a.z) / n1;
+    a.w = a.w + (lw - a.w) / n1;
+    hdr[i] = a;
+}
+
 hipError_t launch_resolve(const DevScene& s, const DevWork& w, hipStream_t st)
 {
     if (w.n_items == 0) return hipSuccess;
+    const uint64_t n = (uint64_t)3 * s.imageW * s.imageH;
+    if (w.nframes == 1u && w.n_items == s.imageW * s.imageH && (n & 3u) == 0u && ((uintptr_t)w.hdr & 15u) == 0u && ((uintptr_t)w.lbuf & 15u) == 0u) {
+        const uint32_t n4 = (uint32_t)(n >> 2);
+        hipLaunchKernelGGL(k_mean_flat, dim3((n4 + 255u) / 256u), dim3(256), 0, st, reinterpret_cast<float4*>(w.hdr), reinterpret_cast<const float4*>(w.lbuf), n4, w.frame0, w.nan_guard);
+        if (w.img) hipLaunchKernelGGL(k_tonemap, dim3((w.n_items + 255u) / 256u), dim3(256), 0, st, s, w);
+        return hipGetLastError();
+    }
     uint32_t blocks = (w.n_items + 255u) / 256u;
     hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, st, s, w);
     return hipGetLastError();

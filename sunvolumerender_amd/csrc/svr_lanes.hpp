@@ -22,6 +22,7 @@
 // order on its own generator, so the radiance is bit-identical to the straight-line code of trace_path_tile.
 #pragma once
 #include "svr_walk.hpp"
+#include "svr_tile_tasks.hpp"
 
 namespace svr {
 
@@ -234,9 +235,11 @@ SVR_DEV void queue_push_a(const LaneQueue& Q, uint32_t& nA, bool live, const Sha
 // stores its radiance at row (id >> 6) * 3 + channel, column id & 63.
 // POOL builds (traceDepth 1): `primary` = the records are P records (camera rays): a lane pops one, walks it, and settles it --
 // the nearest light or the environment (the path is over) or a collision, which becomes an H record (nH counts them).
-template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS, bool POOL = false, bool HIT_B = false>
+// DIRECT (launches that do not fold: frames traced ahead): a finished path writes its radiance straight to its scratch slot (wk / tasks: the launch
+// and the wave's pending task numbers, svr_tile_tasks.hpp direct_put) instead of the task's row.
+template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS, bool POOL = false, bool HIT_B = false, bool DIRECT = false>
 SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, uint32_t nC, uint32_t nA, uint32_t nB0, uint32_t traceDepth_, float* pendL, uint32_t pend_row, Cnt& c,
-                         unsigned long long* c_prof = nullptr, const bool primary = false, uint32_t* nH = nullptr)
+                         unsigned long long* c_prof = nullptr, const bool primary = false, uint32_t* nH = nullptr, const DevWork* wk = nullptr, const uint32_t* tasks = nullptr)
 {
     enum : uint32_t { IDLE = 0u, CELL = 1u, WALK = 2u, FETCH = 3u, MARCH = 4u, END = 5u, WANT_A = 6u, WANT_B = 7u };
     const float INF = u2f(SVR_INF_BITS);
@@ -389,8 +392,11 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
     };
     // a finished path hands its radiance to its task's row
     auto finish = [&]() {
-        float* o = pendL + (id >> 6) * 3u * pend_row + (id & 63u);
-        o[0] = L.x; o[pend_row] = L.y; o[2u * pend_row] = L.z;
+        if constexpr (DIRECT) direct_put(s, *wk, tasks, id, L);
+        else {
+            float* o = pendL + (id >> 6) * 3u * pend_row + (id & 63u);
+            o[0] = L.x; o[pend_row] = L.y; o[2u * pend_row] = L.z;
+        }
         st = IDLE;
     };
     // END of a SHADOW walk (pathtracer.cu:191-198): transmittance -> direct light

@@ -75,4 +75,20 @@ SVR_DEV void fold_pending(const DevScene& s, const DevWork& w, const float* rows
     }
 }
 
+// Launches that do NOT fold (frames traced ahead of the calls that ask for them, svr_api.hip: k_resolve / k_mean_flat fold one scratch slot
+// per call): the radiance of the path with id = (pending task << 6 | lane) of this wave goes straight to lbuf[frame slot][pixel].
+// tasks: the wave's pending task numbers (LDS).
+SVR_DEV void direct_put(const DevScene& s, const DevWork& w, const uint32_t* tasks, uint32_t id, v3 L)
+{
+    const TaskShape ts = task_shape(w);
+    uint32_t tx, ty, fg;
+    task_decode(ts, tasks[id >> 6], tx, ty, fg);
+    const uint32_t ln = id & 63u, pl = ln & ((1u << ts.P2) - 1u), fs = ln >> ts.P2;
+    const uint32_t px = (tx << ts.tw2) + (pl & ((1u << ts.tw2) - 1u));
+    const uint32_t r = (ty << ts.th2) + (pl >> ts.tw2);
+    const uint32_t x = w.x0 + px, y = owned_row_to_y(w, r), slot = (fg << ts.fl2) + fs;
+    float* o = w.lbuf + (size_t)slot * w.slot_stride + 3 * ((size_t)y * s.imageW + x);
+    o[0] = L.x; o[1] = L.y; o[2] = L.z;
+}
+
 } // namespace svr

@@ -251,6 +251,19 @@ SVR_DEV float walk_lm(const DevScene& s, const LDS& L, v3 orig, v3 dir, Rng& rng
     return -SVR_FLT_MAX;
 }
 
+// Phase profile of experiment builds (-DSVR_TEST_HOOKS; tools/lm_phase_prof.py): wave time (s_memtime) per phase of the pool kernel and the same
+// weighted by the lanes that had work in it, accumulated PER WAVE and added to the counters once, when the wave ends (an atomic per phase
+// and turn would be what the profile measures).
+#if SVR_PROF
+struct ProfLocal { unsigned long long cyc[PH_N], lc[PH_N]; };
+#define LPROF_BEGIN(name) const uint64_t name = __builtin_amdgcn_s_memtime()
+#define LPROF_END(name, ph, lanes) do { const uint64_t dt_ = __builtin_amdgcn_s_memtime() - name; pl.cyc[ph] += dt_; pl.lc[ph] += dt_ * (uint64_t)(lanes); } while (0)
+#else
+struct ProfLocal {};
+#define LPROF_BEGIN(name)
+#define LPROF_END(name, ph, lanes)
+#endif
+
 #ifndef SVR_LM_WAVES_PER_EU
 #define SVR_LM_WAVES_PER_EU 4
 #endif
@@ -370,7 +383,10 @@ SVR_DEV v3 trace_path_lm(const DevScene& s, const LDS& L_, uint32_t x, uint32_t 
 // svr_trace_tile.hip.  Every path executes the operations of trace_path_lm in the same order on its own generator, so the
 // pool is scheduling only: bit-identical to the straight-line form (tests/test_local_majorant_gpu.py).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t LM_BATCH = 16;                         // tasks per batch: <= LM_CAP ray records
+#ifndef SVR_LM_BATCH
+#define SVR_LM_BATCH 16
+#endif
+constexpr uint32_t LM_BATCH = SVR_LM_BATCH;               // tasks per batch: <= LM_CAP ray records
 constexpr uint32_t LM_CAP = LM_BATCH * 64;
 constexpr uint32_t LM_RAY_WORDS = 17;                     // o(3) d(3) rng(6) meta p0..p3
 constexpr uint32_t LM_HIT_WORDS = 14;                     // pt(3) wo(3) val rng(6) meta
@@ -381,7 +397,7 @@ SVR_DEV uint32_t lm_meta(uint32_t id, uint32_t light) { return id | (light << 12
 
 template <int LAYOUT, bool COUNT, typename LDS>
 SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, uint32_t n, const bool shadows, uint32_t* H, uint32_t& nH,
-                          float* pendL, Cnt& c)
+                          float* pendL, Cnt& c, ProfLocal& pl)
 {
     enum : uint32_t { IDLE = 0u, WALK = 1u, TENT = 2u, END = 3u };
     const LmGrid g = lm_grid(s);
@@ -410,6 +426,7 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
             const uint64_t idle = __ballot(st == IDLE);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (next < n && (n_idle >= refill_min || __ballot(st == WALK || st == TENT) == 0ull)) {
+                LPROF_BEGIN(prf);
                 const uint32_t i = next + lane_rank(idle);
                 if (st == IDLE && i < n) {
                     const uint32_t* r = R + i;
@@ -435,27 +452,41 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
                     }
                 }
                 next = min(n, next + n_idle);
+                LPROF_END(prf, PH_REFILL, min(n_idle, 64u));
             }
         }
         if (__ballot(st != IDLE) == 0ull) break;                          // no record left, no walk in flight
         // ---- DDA: the walking lanes go on towards their next tentative collision (a few cells per turn) ----
-        #pragma nounroll
-        for (uint32_t k = 0; k < steps_per_turn && __ballot(st == WALK) != 0ull; ++k)
-            if (st == WALK) {
-                const int r = lm_step<COUNT>(s, L_, g, wk, c);
-                st = r == 0 ? WALK : (r == 1 ? TENT : END);
-            }
+        {
+            LPROF_BEGIN(pdd);
+#if SVR_PROF
+            const uint32_t n_walk = (uint32_t)__popcll(__ballot(st == WALK));
+#endif
+            #pragma nounroll
+            for (uint32_t k = 0; k < steps_per_turn && __ballot(st == WALK) != 0ull; ++k)
+                if (st == WALK) {
+                    const int r = lm_step<COUNT>(s, L_, g, wk, c);
+                    st = r == 0 ? WALK : (r == 1 ? TENT : END);
+                }
+            LPROF_END(pdd, PH_CHEAP, n_walk);
+        }
         // ---- tentative collisions: fetch + accept test ----
         if (__ballot(st == TENT) != 0ull) {
+            LPROF_BEGIN(pte);
+#if SVR_PROF
+            const uint32_t n_tent = (uint32_t)__popcll(__ballot(st == TENT));
+#endif
             if (st == TENT) {
                 hit = lm_tentative<LAYOUT, COUNT>(s, L_, g, wk, o, d, rng, val, c);
                 st = hit ? END : WALK;
             }
+            LPROF_END(pte, PH_FETCH, n_tent);
         }
         // ---- settle the walks that are over (when they are many, or nothing else is left to do) ----
         {
             const uint64_t ended = __ballot(st == END);
             if (ended != 0ull && ((uint32_t)__popcll(ended) >= ended_min || __ballot(st == WALK || st == TENT) == 0ull)) {
+                LPROF_BEGIN(pse);
                 if (shadows) {
                     if (st == END) {
                         // estimate_direct_light's tail (pathtracer.cu:191-198): p0..p2 = bsdf, p3 = pdf
@@ -490,6 +521,7 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
                     }
                     nH += (uint32_t)__popcll(mh);
                 }
+                LPROF_END(pse, PH_END, (uint32_t)__popcll(ended));
             }
         }
     }
@@ -514,6 +546,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
     uint32_t* const R = w.queue + wslot * (REC_WORDS * QUEUE_CAP);       // ray records
     uint32_t* const H = R + (size_t)LM_RAY_WORDS * LM_CAP;               // hit records
     Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ProfLocal pl = {};
     auto fence = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // records and radiance rows are read back by other lanes of this wave
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -521,6 +554,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
     uint32_t si = 0u;                                                     // ticket counters visited so far
     for (;;) {
         // ---- gen: up to LM_BATCH tasks ----
+        LPROF_BEGIN(pgen);
         uint32_t nb = 0u, nR = 0u;
         while (nb < LM_BATCH && si < TICKET_SHARDS) {
             const uint32_t shard = (shard0 + si) % TICKET_SHARDS;
@@ -596,13 +630,15 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             if (lane == 0) pend_task[wave][nb] = k;
             ++nb;
         }
+        LPROF_END(pgen, PH_PRIMARY, 64u);
         if (nb == 0u) break;
         // ---- walk: primary rays ----
         uint32_t nH = 0u;
         fence();
-        lm_walk_pool<LAYOUT, COUNT>(s, lds, R, nR, false, H, nH, gpend, c);
+        lm_walk_pool<LAYOUT, COUNT>(s, lds, R, nR, false, H, nH, gpend, c, pl);
         fence();
         // ---- shade the collisions, 64 at a time: each becomes a shadow ray (or ends with L = 0) ----
+        LPROF_BEGIN(psh);
         uint32_t nS = 0u;
         for (uint32_t i0 = 0u; i0 < nH; i0 += 64u) {
             const uint32_t i = i0 + lane;
@@ -636,15 +672,22 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             }
             nS += (uint32_t)__popcll(ms);
         }
+        LPROF_END(psh, PH_SHADE, nH ? min(64u, (nH + ((nH + 63u) >> 6) - 1u) / ((nH + 63u) >> 6)) : 0u);
         // ---- walk: shadow rays ----
         fence();
         uint32_t none = 0u;
-        lm_walk_pool<LAYOUT, COUNT>(s, lds, R, nS, true, H, none, gpend, c);
+        lm_walk_pool<LAYOUT, COUNT>(s, lds, R, nS, true, H, none, gpend, c, pl);
         fence();
         // ---- fold the batch ----
+        LPROF_BEGIN(pfo);
         fold_pending(s, w, gpend, 64u, &pend_task[wave][0], nb);
         fence();
+        LPROF_END(pfo, PH_FOLD, 48u);
     }
+#if SVR_PROF
+    if (lane == 0u)
+        for (uint32_t ph = 0; ph < PH_N; ++ph) { atomicAdd(&w.counters[CNT_N + 2 * ph], pl.cyc[ph]); atomicAdd(&w.counters[CNT_N + 2 * ph + 1], pl.lc[ph]); }
+#endif
     if (COUNT) cnt_flush(w, c);
 }
 

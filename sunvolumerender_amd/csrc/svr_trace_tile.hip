@@ -256,10 +256,13 @@ struct LdsPendQueue {                              // QUEUE builds: only the tas
 // transparent space, c3n): the primary walks are pooled too.  A task only generates its camera rays (P records); at a flush the lane
 // machine walks them (a lane pops a ray, walks, settles, pops the next), the collisions are shaded 64 at a time into C1 records, and
 // the machine walks those -- the wave-sized wavefront of svr_trace_lm.hip with the bit-exact walk.  Scheduling only.
-template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, bool QUEUE, bool POOL = false>
+// DIRECT (QUEUE builds, launches that do not fold: frames traced ahead of the calls that ask for them): a path's radiance goes straight to its scratch slot
+// lbuf[frame][pixel] when it is final, instead of through the wave's rows and a fold.
+template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, bool QUEUE, bool POOL = false, bool DIRECT = false>
 __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_trace_tile(const DevScene s, const DevWork w)
 {
     static_assert(!POOL || (QUEUE && SKIP), "the pool form exists for skipping builds with the queue machine");
+    static_assert(!DIRECT || QUEUE, "the straight-line builds write their scratch slots anyway");
     using LDS = typename std::conditional<SKIP, LdsTileCull, LdsTileNoMask>::type;
     __shared__ LDS lds;
     __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
@@ -302,14 +305,14 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 // deeper paths: qC camera rays (P records) -> collisions = B records (first scatter events, unshaded) of the machine below
                 static_assert(REC_C1_WORDS <= REC_A_WORDS, "P records lie in front of the B stack");
                 uint32_t nH = 0u;
-                drain_queue<LAYOUT, COUNT, SKIP, true, LDS, true, true>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH);
+                drain_queue<LAYOUT, COUNT, SKIP, true, LDS, true, true, DIRECT>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH, &w, &pend.task[wave][0]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 qC = 0u; qA = 0u; qB = nH;
             } else if constexpr (POOL) {
                 // qC camera rays (P records) -> collisions (H records) -> shaded, 64 at a time -> C1 records -> their shadow walks
                 uint32_t nH = 0u;
-                drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, true>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH);
+                drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, true, false, DIRECT>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH, &w, &pend.task[wave][0]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 qC = 0u;
@@ -331,8 +334,11 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                         shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
                         have = ne.have;
                         if (!have) {                                          // a first event no light sample reaches: L = 0
-                            float* o = gpend + (id >> 6) * (3u * 64u) + (id & 63u);
-                            o[0] = 0.f; o[64] = 0.f; o[128] = 0.f;
+                            if constexpr (DIRECT) direct_put(s, w, &pend.task[wave][0], id, V3(0.f, 0.f, 0.f));
+                            else {
+                                float* o = gpend + (id >> 6) * (3u * 64u) + (id & 63u);
+                                o[0] = 0.f; o[64] = 0.f; o[128] = 0.f;
+                            }
                         }
                     }
                     queue_push_c1(Q, qC, have, vs.pt, ne, rng, id);
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1>(s, lds, Q, qC, qA, qB, w.traceDepth, gpend, 64u, c, w.counters + CNT_N);
+            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, false, false, DIRECT>(s, lds, Q, qC, qA, qB, w.traceDepth, gpend, 64u, c, w.counters + CNT_N, false, nullptr, &w, &pend.task[wave][0]);
             qC = qA = qB = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
             unsigned long long* c_prof = w.counters + CNT_N;
 #endif
             PROF_BEGIN(pfo, PH_FOLD);
-            fold_pending(s, w, gpend, 64u, &pend.task[wave][0], npend);
+            if constexpr (!DIRECT) fold_pending(s, w, gpend, 64u, &pend.task[wave][0], npend);
             PROF_END(pfo, min(64u, npend * (3u << ts.P2)));
         } else {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // pend.L / pend.task are written by one lane and read by another lane of this wave
@@ -414,8 +420,15 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                         qC += (uint32_t)__popcll(m);
                     }
                     if (!queued) {
-                        float* o = gpend + (size_t)npend * (3u * 64u) + lane;
-                        o[0] = L.x; o[64] = L.y; o[128] = L.z;
+                        if constexpr (DIRECT) {
+                            if (live) {
+                                float* o = w.lbuf + (size_t)slot * w.slot_stride + 3 * ((size_t)owned_row_to_y(w, r) * s.imageW + (w.x0 + px));
+                                o[0] = L.x; o[1] = L.y; o[2] = L.z;
+                            }
+                        } else {
+                            float* o = gpend + (size_t)npend * (3u * 64u) + lane;
+                            o[0] = L.x; o[64] = L.y; o[128] = L.z;
+                        }
                     }
                     if (lane == 0) pend.task[wave][npend] = k;
                     if (++npend == QUEUE_TASKS || qC + 64u > QUEUE_CAP) flush();
@@ -490,8 +503,15 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                         over = !hit;
                     }
                     if (over) {
-                        float* o = gpend + (size_t)npend * (3u * 64u) + lane;
-                        o[0] = L.x; o[64] = L.y; o[128] = L.z;
+                        if constexpr (DIRECT) {
+                            if (live) {
+                                float* o = w.lbuf + (size_t)slot * w.slot_stride + 3 * ((size_t)owned_row_to_y(w, r) * s.imageW + (w.x0 + px));
+                                o[0] = L.x; o[1] = L.y; o[2] = L.z;
+                            }
+                        } else {
+                            float* o = gpend + (size_t)npend * (3u * 64u) + lane;
+                            o[0] = L.x; o[64] = L.y; o[128] = L.z;
+                        }
                     }
                     if (lane == 0) pend.task[wave][npend] = k;
                     if (++npend == QUEUE_TASKS || qC + qA + qB + 64u > QUEUE_CAP) flush();
@@ -557,8 +577,22 @@ static hipError_t launch_tile_t(const DevScene& s, const DevWork& w, const Launc
     if (e != hipSuccess) return e;
     const bool skip = s.empty_mask != nullptr, d1 = w.traceDepth == 1u;
     // QUEUE builds need the per-wave record queues (DevWork.queue, sized for `queue_blocks` blocks) and exist for the BRICK layout only
-    const bool queue = LAYOUT != LAYOUT_LINEAR && w.fold && w.queue != nullptr && w.pend != nullptr && blocks <= w.queue_blocks && w.traceDepth < 32768u;   // a record's bounce counter has 15 bits
+    // (launches that do not fold -- frames traced ahead -- have the queue builds in their DIRECT form, which is not built with counters)
+    const bool queue = LAYOUT != LAYOUT_LINEAR && w.queue != nullptr && w.pend != nullptr && blocks <= w.queue_blocks && w.traceDepth < 32768u &&   // a record's bounce counter has 15 bits
+                       (w.fold || !COUNT);
 #define SVR_LAUNCH_TILE(SK, D1, QU) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, SK, D1, QU>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2)
+    if constexpr (LAYOUT != LAYOUT_LINEAR && !COUNT) {
+        if (queue && !w.fold) {
+#define SVR_LAUNCH_DIRECT(SK, D1, PO) hipLaunchKernelGGL((k_trace_tile<LAYOUT, false, SK, D1, true, PO, true>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2)
+            if (skip && cfg.pool_primary) { if (d1) SVR_LAUNCH_DIRECT(true, true, true); else SVR_LAUNCH_DIRECT(true, false, true); }
+            else if (skip && d1) SVR_LAUNCH_DIRECT(true, true, false);
+            else if (skip) SVR_LAUNCH_DIRECT(true, false, false);
+            else if (d1) SVR_LAUNCH_DIRECT(false, true, false);
+            else SVR_LAUNCH_DIRECT(false, false, false);
+#undef SVR_LAUNCH_DIRECT
+            return hipGetLastError();
+        }
+    }
     if constexpr (LAYOUT != LAYOUT_LINEAR) {
         if (queue && skip && cfg.pool_primary) {
             if (d1) hipLaunchKernelGGL((k_trace_tile<LAYOUT, COUNT, true, true, true, true>), dim3(blocks), dim3(SVR_TILE_THREADS), 0, st, s, w2);

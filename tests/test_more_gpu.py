@@ -516,6 +516,33 @@ def test_frame_ahead_matches_per_frame_calls(hip_dev):
             canvas.close()
 
 
+@pytest.mark.parametrize("name,depth", [("tiny_head", 1), ("tiny_head_noisy", 1), ("tiny_head", 2), ("tiny_bone", 4)])
+def test_frame_ahead_steady_state_with_a_sync_per_call(hip_dev, name, depth):
+    """The reference's host protocol, gui/canvas.cpp:96-116: render_pathtracer, cudaDeviceSynchronize, frameNo++ -- 200 times, i.e. well
+    into the steady state of frame-ahead tracing (64-frame batches traced by the queue builds of the tile kernel into scratch slots while
+    the previous batch is consumed; svr_device_synchronize waits for the caller's stream only).  The accumulator and the image after
+    frames 100 and 200 are the oracle's, bit for bit; tiny_head_noisy runs the pooled primary walks, depth 2 / 4 the lane machine."""
+    sc = scenes.make_scene(name, trace_depth=depth)
+    o = binding.OracleScene(sc)
+    acc = o.new_hdr()
+    img = np.zeros((o.H, o.W, 4), dtype=np.uint8)
+    refs = {}
+    for f in range(200):
+        o.render_pathtracer(acc, f, trace_depth=depth, img=img, count=False)
+        if f + 1 in (100, 200):
+            refs[f + 1] = (acc.copy(), img.copy())
+    canvas = host.Canvas(hip_dev, sc.width, sc.height)
+    try:
+        scenes.apply_to_canvas(sc, canvas)
+        for f in range(200):
+            canvas.paint(sync=True)
+            if f + 1 in refs:
+                assert_bit_exact(canvas.read_hdr(), refs[f + 1][0], f"{name} depth {depth}: {f + 1} calls, one sync per call")
+                assert np.array_equal(canvas.read_img(), refs[f + 1][1])
+    finally:
+        canvas.close()
+
+
 @pytest.mark.parametrize("eye", [30.0, 47.9, 130.0, 1000.0, 4100.0, 70000.0])
 def test_raycasting_sample_chain_replay(hip_dev, eye):
     """The ray caster replays the float chain t += h in closed form to skip transparent stretches.  Eye distances

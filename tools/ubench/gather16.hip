@@ -8,6 +8,9 @@
 //   pattern 0: every lane its own uniformly random 16-byte element (the walk of a fog-like medium)
 //   pattern 1: the 64 lanes of a wave in ONE random 2-KB brick (8 x 4 x 4 elements: a coherent wave)
 //   pattern 2: dependent chain -- the next index comes from the loaded value (latency of one gather)
+//   pattern 3: 8 adjacent lanes read the 8 elements of ONE random 128-byte line (8 whole lines per wave instruction): if a 16-byte gather
+//              that misses moved a whole line, lines per second would be the same as in pattern 0
+//   pattern 4: 4 adjacent lanes read one random 64-byte half line (16 half lines per wave instruction)
 // prints: requests, ms, G gathers/s, requested GB/s (16 B each)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -44,6 +47,11 @@ __global__ __launch_bounds__(1024) void k_gather16(const uint4* __restrict__ t, 
             if (PATTERN == 1) {
                 const uint32_t b = wang(wave * 0x9e3779b9u + (i + j) * 0x85ebca6bu) % (n_elems >> 7);
                 idx = (b << 7) + ((lane * 37u + i + j) & 127u);
+            } else if (PATTERN == 3 || PATTERN == 4) {
+                constexpr uint32_t G = PATTERN == 3 ? 8u : 4u;                       // lanes per group = elements per piece
+                const uint32_t grp = gid / G;
+                const uint32_t h = wang(grp * 0x9e3779b9u + (i + j) * 0x85ebca6bu + 77u);
+                idx = (uint32_t)(((uint64_t)h * (n_elems / G)) >> 32) * G + (lane & (G - 1u));
             } else {
                 x = x * 1664525u + 1013904223u;
                 idx = (uint32_t)(((uint64_t)wang(x) * n_elems) >> 32);
@@ -64,7 +72,9 @@ static void launch(int pattern, int blocks, const uint4* t, uint32_t n, uint32_t
 {
     if (pattern == 0) hipLaunchKernelGGL((k_gather16<ILP, 0>), dim3(blocks), dim3(1024), 0, 0, t, n, iters, out);
     else if (pattern == 1) hipLaunchKernelGGL((k_gather16<ILP, 1>), dim3(blocks), dim3(1024), 0, 0, t, n, iters, out);
-    else hipLaunchKernelGGL((k_gather16<ILP, 2>), dim3(blocks), dim3(1024), 0, 0, t, n, iters, out);
+    else if (pattern == 2) hipLaunchKernelGGL((k_gather16<ILP, 2>), dim3(blocks), dim3(1024), 0, 0, t, n, iters, out);
+    else if (pattern == 3) hipLaunchKernelGGL((k_gather16<ILP, 3>), dim3(blocks), dim3(1024), 0, 0, t, n, iters, out);
+    else hipLaunchKernelGGL((k_gather16<ILP, 4>), dim3(blocks), dim3(1024), 0, 0, t, n, iters, out);
 }
 
 int main(int argc, char** argv)
