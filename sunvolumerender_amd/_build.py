@@ -17,14 +17,14 @@ CSRC = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
 LIB_PATH = Path(os.environ["SVR_HIP_LIB"]) if os.environ.get("SVR_HIP_LIB") else LIB_DIR / "libsvr_hip.so"
 
-HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_wavefront.hip", "svr_accel.hip", "svr_raycast.hip", "svr_host_io.hip", "svr_volume_prep.hip", "svr_selftest.hip", "svr_trace_tile_fast.hip", "svr_trace_lm.hip"]
+HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_wavefront.hip", "svr_accel.hip", "svr_raycast.hip", "svr_host_io.hip", "svr_volume_prep.hip", "svr_selftest.hip", "svr_trace_tile_fast.hip", "svr_trace_lm.hip", "svr_trace_split.hip"]
 # svr_trace_tile_fast.hip (the opt-in fast-math build) includes svr_trace_tile.hip and is compiled WITHOUT the contract flags
 FAST_SOURCES = {"svr_trace_tile_fast.hip"}
 CONTRACT_FLAGS = {"-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"}
 # (full -ffast-math, and hardware exp / sin / cos in place of the polynomial versions, cost 50-60 spilled VGPRs in this kernel
 # and made it 38 % SLOWER; the walk's logarithm + reciprocal division + contraction keep the register allocation)
 FAST_FLAGS = ["-ffp-contract=fast", "-freciprocal-math", "-fno-signed-zeros"]
-HIP_HEADERS = ["svr_trace_tile.hip", "svr_math.hpp", "svr_scene.hpp", "svr_device.hpp", "svr_kernels.hpp", "svr_kernel_common.hpp", "svr_walk.hpp", "svr_lanes.hpp", "svr_tile_tasks.hpp"]
+HIP_HEADERS = ["svr_trace_tile.hip", "svr_math.hpp", "svr_scene.hpp", "svr_device.hpp", "svr_kernels.hpp", "svr_kernel_common.hpp", "svr_walk.hpp", "svr_lanes.hpp", "svr_tile_tasks.hpp", "svr_primary.hpp"]
 
 HIPCC_FLAGS = [
     "-O3",

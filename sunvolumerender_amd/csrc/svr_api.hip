@@ -89,6 +89,9 @@ struct Context {
     uint32_t queue_blocks = 0;          // blocks both are sized for
     bool queue_alloc_failed = false;    // SVR_OPT_QUEUE = 1 and the device had no room for them: straight-line launches
     hipEvent_t prev_traced = nullptr;   // `traced` event of the latest trace launch (owned by its set)
+    uint32_t* d_split_pool = nullptr;   // chunks of path records of the split kernels of deeper paths (svr_trace_split.hip)
+    uint64_t split_chunks = 0;
+    bool split_alloc_failed = false;
     hipEvent_t queue_done = nullptr;    // recorded behind every launch that uses d_queue / d_pend (there is ONE such memory: its users run one after the other, on whatever stream)
     bool queue_used = false;
     // frames traced ahead of the host's render_pathtracer calls (render_frames)
@@ -124,7 +127,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1, opt_nan_guard = 0, opt_macro_shift_min = 0;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1, opt_nan_guard = 0, opt_macro_shift_min = 0, opt_split = 1;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -213,8 +216,8 @@ int ensure_init()
     g.info = buf;
     HIP_TRY(hipMalloc((void**)&g.d_counters, sizeof(svr_counters) + DEBUG_WORDS * 8));       // + the phase profile of experiment builds
     HIP_TRY(hipMemset(g.d_counters, 0, sizeof(svr_counters) + DEBUG_WORDS * 8));
-    HIP_TRY(hipMalloc((void**)&g.d_ticket, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * (Context::NSETS + 1)));
-    HIP_TRY(hipMemset(g.d_ticket, 0, sizeof(uint32_t) * svr::TICKET_SHARDS * svr::TICKET_STRIDE * (Context::NSETS + 1)));
+    HIP_TRY(hipMalloc((void**)&g.d_ticket, sizeof(uint32_t) * (svr::TICKET_SHARDS * svr::TICKET_STRIDE * (Context::NSETS + 1) + 64)));       // (+ the chunk counters of the split kernels behind the last set of task counters)
+    HIP_TRY(hipMemset(g.d_ticket, 0, sizeof(uint32_t) * (svr::TICKET_SHARDS * svr::TICKET_STRIDE * (Context::NSETS + 1) + 64)));
     HIP_TRY(hipMalloc((void**)&g.d_mask, svr::ACCEL_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&g.d_mask_tmp, 2 * (size_t)svr::MASK_WORDS_MAX * 32));
     for (int i = 0; i < Context::NSETS; ++i) {
@@ -598,6 +601,24 @@ int ensure_record_queues(uint32_t blocks, bool soft, bool& available)
     return 0;
 }
 
+// the chunk pool of the split kernels (svr_trace_split.hip): worst case of the largest launch so far; soft -- without room for it the fused kernel renders
+int ensure_split_pool(uint64_t chunks, bool& available)
+{
+    available = true;
+    if (g.d_split_pool && g.split_chunks >= chunks) return 0;
+    if (g.split_alloc_failed) { available = false; return 0; }
+    HIP_TRY(hipDeviceSynchronize());
+    if (g.d_split_pool) { HIP_TRY(hipFree(g.d_split_pool)); g.d_split_pool = nullptr; g.split_chunks = 0; }
+    hipError_t e = hipMalloc((void**)&g.d_split_pool, (size_t)chunks * svr::SPLIT_CHUNK_WORDS * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        g.d_split_pool = nullptr;
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); g.split_alloc_failed = true; available = false; return 0; }
+        return fail((int)e, "HIP error allocating the record pool of the split kernels (%zu MB): %s", ((size_t)chunks * svr::SPLIT_CHUNK_WORDS * 4) >> 20, hipGetErrorName(e));
+    }
+    g.split_chunks = chunks;
+    return 0;
+}
+
 int ensure_queues(uint32_t W, uint32_t H)
 {
     size_t need = (size_t)W * H * Context::GROUP;
@@ -677,11 +698,36 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         if (ensure_record_queues((uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u / 16u, g.opt_queue == 1 && !local_majorant, available)) return g.err_code;
         use_queue = use_queue && available;
     }
+    const bool frame_ahead_possible = nframes == 1 && g.opt_frame_ahead && g.opt_pipeline && !g.opt_count && !g.opt_debug_stop && cfg.kernel == svr::KERNEL_TILE;
+    // Deeper paths, bit-exact, as TWO kernels (svr_trace_split.hip: front half -> chunks of records -> lane machine; the launch's frames go through
+    // the scratch slots and k_resolve): where the fused queue kernel would run and its primary walks are not pooled, the image fits a 26-bit pixel
+    // index, and the device has room for the worst-case record pool of a launch (<= 24 GB; else the fused kernel)
+    bool use_split = false;
+    const uint32_t split_group = (uint32_t)g.opt_group_frames;
+    // (same-box A/B, c3: depth 2 4 750 against the fused kernel's 4 884 Msamples/s, depth 4 3 029 against 2 978, depth 6 2 745 against 2 699: the scratch
+    // slots and the second launch cost ~0.4 ms per 64 frames, which the machine's own register budget wins back from three bounces on -> auto = depth >= 3)
+    if (g.opt_split && use_queue && rp->traceDepth >= (g.opt_split == 2 ? 2u : 3u) && rp->traceDepth < 32768u && !cfg.pool_primary && !local_majorant && !g.opt_fast_math && nframes >= 8 &&
+        s.layout != svr::LAYOUT_LINEAR && (uint64_t)s.imageW * s.imageH <= (1ull << 26) && !frame_ahead_possible) {
+        svr::DevWork wq;
+        fill_work(wq, s.imageW, s.imageH);
+        const uint32_t n_max = nframes < split_group ? nframes : split_group;
+        uint32_t fl2 = 0;
+        while ((1u << fl2) < n_max) ++fl2;
+        const uint32_t P2 = 6u - fl2, tw2 = (P2 + 1u) >> 1, th2 = P2 >> 1;
+        const uint64_t n_tasks = (uint64_t)((wq.x1 - wq.x0 + (1u << tw2) - 1u) >> tw2) * ((wq.n_rows + (1u << th2) - 1u) >> th2);
+        const uint64_t chunks = svr::split_chunks_worst_case(n_tasks * 64u, (uint32_t)(cfg.num_cus * cfg.blocks_per_cu) * 4u);
+        if (chunks * svr::SPLIT_CHUNK_WORDS * sizeof(uint32_t) <= (24ull << 30) && chunks < (1ull << 31)) {
+            bool available = true;
+            if (ensure_split_pool(chunks, available)) return g.err_code;
+            use_split = available;
+        }
+        if (use_split && ensure_slots(s.imageW, s.imageH, n_max < (uint32_t)Context::GROUP ? (uint32_t)Context::GROUP : n_max)) return g.err_code;
+    }
     auto launch_tile = [&](const svr::DevWork& w, hipStream_t st) -> hipError_t {
         if (local_majorant) return svr::launch_trace_lm(s, w, cfg, st);
         return g.opt_fast_math ? svr_fast::launch_trace_tile_raw(&s, &w, &cfg, st) : svr::launch_trace_tile(s, w, cfg, st);
     };
-    const bool frame_ahead_call = nframes == 1 && g.opt_frame_ahead && g.opt_pipeline && !g.opt_count && !g.opt_debug_stop && cfg.kernel == svr::KERNEL_TILE;
+    const bool frame_ahead_call = frame_ahead_possible;
     // short launches (< FOLD_MIN frames) keep the slots: they end in a tail of a few long tasks that only overlapping launches
     // on several streams hide, and a folding launch cannot overlap its predecessor (measured, 1 frame per call: 0.276 vs 0.366 ms)
     constexpr uint32_t FOLD_MIN = 8;
@@ -786,6 +832,42 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     };
     auto next_set = [&]() { int si = g.next_set; g.next_set = (g.next_set + 1) % Context::NSETS; return si; };
     const bool want_img = tonemap && !g.opt_skip_tonemap;
+    // one launch of the split kernels (n <= 64 frames of every owned pixel) + the fold of its scratch slots, all on the caller's stream
+    auto trace_split = [&](uint32_t first, uint32_t n, bool img_now) -> int {
+        const int si = next_set();
+        Context::SlotSet& set = g.sets[si];
+        for (auto& a : g.ahead) if (a.valid && a.set == si) a.valid = false;     // its slots are about to be overwritten
+        if (set.used) HIP_TRY(hipStreamWaitEvent(g.stream, set.traced, 0));       // (a batch still being traced ahead into this set)
+        svr::DevWork w;
+        fill_work(w, s.imageW, s.imageH);
+        w.hdr = (float*)rp->hdrBuffer;
+        w.img = img_now ? (uint8_t*)img : nullptr;
+        w.lbuf = set.lbuf;
+        w.slot_stride = (uint32_t)g.slot_floats;
+        w.ticket = g.d_ticket + (size_t)svr::TICKET_SHARDS * svr::TICKET_STRIDE * Context::NSETS;
+        w.traceDepth = rp->traceDepth;
+        w.frame0 = first;
+        w.nframes = n;
+        w.queue = g.d_split_pool;
+        w.queue_blocks = (uint32_t)g.split_chunks;
+        int slot = -1;
+        if (g.opt_timing) {
+            if (g.ev_count == Context::EV_RING) collect_timing();
+            slot = g.ev_head;
+            HIP_TRY(hipEventRecord(g.ev0[slot], g.stream));
+        }
+        HIP_TRY(svr::launch_trace_split(s, w, cfg, g.stream));
+        if (g.opt_timing) {
+            HIP_TRY(hipEventRecord(g.ev1[slot], g.stream));
+            g.ev_head = (g.ev_head + 1) % Context::EV_RING;
+            g.ev_count++;
+        }
+        HIP_TRY(svr::launch_resolve(s, w, g.stream));
+        HIP_TRY(hipEventRecord(set.traced, g.stream));
+        HIP_TRY(hipEventRecord(set.resolved, g.stream));
+        set.used = true;
+        return 0;
+    };
 
     // The reference's host calls render_pathtracer once per frame (gui/canvas.cpp:96).  A frame's radiance is a pure
     // function of (scene, pixel, frame number), so frames can be traced AHEAD of the calls that ask for them: a
@@ -843,7 +925,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         uint32_t n = nframes - g0 < group ? nframes - g0 : group;
         bool last = g0 + n >= nframes;
         if (fold_batch && n >= FOLD_MIN) {
-            if (trace_fold(rp->frameNo + g0, n, want_img && last)) return g.err_code;
+            if (use_split ? trace_split(rp->frameNo + g0, n, want_img && last) : trace_fold(rp->frameNo + g0, n, want_img && last)) return g.err_code;
         } else if (trace_group(next_set(), rp->frameNo + g0, n, n, want_img && last)) return g.err_code;
     }
     return 0;
@@ -902,6 +984,7 @@ void svr_shutdown(void)
     if (g.d_queue) hipFree(g.d_queue);
     if (g.d_pend) hipFree(g.d_pend);
     if (g.queue_done) hipEventDestroy(g.queue_done);
+    if (g.d_split_pool) hipFree(g.d_split_pool);
     if (g_stage) { hipFree(g_stage); g_stage = nullptr; g_stage_floats = 0; }
     for (int i = 0; i < Context::EV_RING; ++i) {
         if (g.ev0[i]) hipEventDestroy(g.ev0[i]);
@@ -1447,6 +1530,9 @@ int svr_set_option(int key, int value)
     case SVR_OPT_PARK_END:
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_END: bad value %d (1..64)", value);
         g.opt_park_end = value; return 0;
+    case SVR_OPT_SPLIT:
+        if (value < 0 || value > 2) return fail(-6, "SVR_OPT_SPLIT: bad value %d (0 off, 1 auto, 2 always)", value);
+        g.opt_split = value; g.split_alloc_failed = false; return 0;
     case SVR_OPT_NAN_GUARD: g.opt_nan_guard = value ? 1 : 0; return 0;
     case SVR_OPT_MACRO_SHIFT_MIN:
         if (value < 0 || value > 6) return fail(-6, "SVR_OPT_MACRO_SHIFT_MIN: bad value %d (0..6)", value);
@@ -1498,6 +1584,7 @@ int svr_get_option(int key)
     case SVR_OPT_PINHOLE_FAST: return g.opt_pinhole_fast;
     case SVR_OPT_POOL: return g.opt_pool;
     case SVR_OPT_TRIPS: return g.opt_trips;
+    case SVR_OPT_SPLIT: return g.opt_split;
     case SVR_OPT_NAN_GUARD: return g.opt_nan_guard;
     case SVR_OPT_MACRO_SHIFT_MIN: return g.opt_macro_shift_min;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;

@@ -27,6 +27,8 @@ constexpr uint32_t QUEUE_CAP = 32 * QUEUE_TASKS;
 constexpr uint32_t TILE_WAVES = 16;
 constexpr size_t QUEUE_WORDS_PER_BLOCK = (size_t)REC_WORDS * QUEUE_CAP * TILE_WAVES;
 constexpr size_t PEND_FLOATS_PER_BLOCK = (size_t)QUEUE_TASKS * 3 * 64 * TILE_WAVES;
+// the split kernels of deeper paths (svr_trace_split.hip): a chunk of the launch-wide record pool = the records, a table of QUEUE_CAP path ids, two counts (+ padding)
+constexpr size_t SPLIT_CHUNK_WORDS = (size_t)REC_WORDS * QUEUE_CAP + QUEUE_CAP + 32;
 // Bound classes (svr_accel.hip, k_bound_class): 4 bits per half-resolution macro-cell = smallest class c whose threshold
 // BOUND_THR(c) is >= (largest transfer-function alpha any fetch in the cell can return) x invSigmaMax.
 constexpr uint32_t BOUND_CLASSES = 16;
@@ -56,6 +58,9 @@ hipError_t launch_pathtrace(const DevScene& scene, const DevWork& work, const La
 hipError_t launch_resolve(const DevScene& scene, const DevWork& work, hipStream_t stream);
 // default trace kernel (svr_trace_tile.hip): persistent waves, one 8x8 tile-task per wave, empty-space skipping
 hipError_t launch_trace_tile(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
+// deeper paths as two kernels (svr_trace_split.hip): front half (primary walks, first events in place) -> chunks of records -> lane machine; radiance to the scratch slots
+hipError_t launch_trace_split(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
+uint64_t split_chunks_worst_case(uint64_t n_paths_padded, uint32_t waves);
 // OPT-IN local-majorant kernel (svr_trace_lm.hip): needs scene.empty_mask (class table) and scene.ray_skip; folding launches need work.pend
 hipError_t launch_trace_lm(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
 // wavefront kernels (svr_wavefront.hip): gen -> [walk -> shade] x depth over dense queues with ballot/prefix-sum

@@ -235,9 +235,10 @@ SVR_DEV void queue_push_a(const LaneQueue& Q, uint32_t& nA, bool live, const Sha
 // stores its radiance at row (id >> 6) * 3 + channel, column id & 63.
 // POOL builds (traceDepth 1): `primary` = the records are P records (camera rays): a lane pops one, walks it, and settles it --
 // the nearest light or the environment (the path is over) or a collision, which becomes an H record (nH counts them).
-// DIRECT (launches that do not fold: frames traced ahead): a finished path writes its radiance straight to its scratch slot (wk / tasks: the launch
-// and the wave's pending task numbers, svr_tile_tasks.hpp direct_put) instead of the task's row.
-template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS, bool POOL = false, bool HIT_B = false, bool DIRECT = false>
+// OUT: where a finished path's radiance goes.  0: its task's row (pendL).  1 (launches that do not fold: frames traced ahead): straight to its scratch
+// slot, found from the wave's pending task numbers (wk / tasks; svr_tile_tasks.hpp direct_put).  2 (the split kernels of deeper paths,
+// svr_trace_split.hip): straight to its scratch slot, found from the chunk's table tasks[id] = frame slot << 26 | pixel index.
+template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS, bool POOL = false, bool HIT_B = false, int OUT = 0>
 SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, uint32_t nC, uint32_t nA, uint32_t nB0, uint32_t traceDepth_, float* pendL, uint32_t pend_row, Cnt& c,
                          unsigned long long* c_prof = nullptr, const bool primary = false, uint32_t* nH = nullptr, const DevWork* wk = nullptr, const uint32_t* tasks = nullptr)
 {
@@ -392,8 +393,12 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
     };
     // a finished path hands its radiance to its task's row
     auto finish = [&]() {
-        if constexpr (DIRECT) direct_put(s, *wk, tasks, id, L);
-        else {
+        if constexpr (OUT == 1) direct_put(s, *wk, tasks, id, L);
+        else if constexpr (OUT == 2) {
+            const uint32_t gid = tasks[id];
+            float* o = wk->lbuf + (size_t)(gid >> 26) * wk->slot_stride + 3 * (size_t)(gid & 0x3ffffffu);
+            o[0] = L.x; o[1] = L.y; o[2] = L.z;
+        } else {
             float* o = pendL + (id >> 6) * 3u * pend_row + (id & 63u);
             o[0] = L.x; o[pend_row] = L.y; o[2u * pend_row] = L.z;
         }

@@ -768,3 +768,25 @@ def test_nan_guard_drops_non_finite_samples(hip_dev, depth):
     assert_bit_exact(g_hdr, g2_hdr, "NAN_GUARD: folding launch vs per-frame calls")
     assert np.array_equal(g_img, g2_img)
     assert (g_hdr[~clean] >= 0).all()
+
+
+@pytest.mark.parametrize("name,depth", [("tiny_head", 2), ("tiny_head", 4), ("tiny_bone", 6), ("small_head", 3), ("odd", 3), ("tiny_head_noisy", 3)])
+def test_split_kernels_bit_exact(hip_dev, name, depth):
+    """Deeper paths as two kernels (csrc/svr_trace_split.hip: front half -> chunks of path records -> lane machine -> scratch slots -> k_resolve),
+    forced on (SVR_OPT_SPLIT = 2: from traceDepth 2) and off, one 70-frame call (a 64-frame and a 6-frame launch: the short one takes the ordinary
+    path) and one 40-frame call; production and counting builds against the oracle: accumulator, image and the reference's counters.
+    (tiny_head_noisy: its primary walks are pooled, so the fused kernel renders whatever the switch says.)"""
+    from tests.test_local_majorant_gpu import _make
+    sc = _make(name, trace_depth=depth)
+    for frames in (70, 40):
+        ref_hdr, ref_img, ref_c = oracle_frames(sc, frames)
+        for split in (2, 0):
+            hip_dev.set_option(abi.OPT_SPLIT, split)
+            try:
+                hdr, img, c = hip_frames(hip_dev, sc, frames, batch=True)
+            finally:
+                hip_dev.set_option(abi.OPT_SPLIT, 1)
+            assert_bit_exact(hdr, ref_hdr, f"{name} depth {depth}, {frames} frames, SVR_OPT_SPLIT = {split}")
+            assert np.array_equal(img, ref_img)
+            assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"]
+            assert c["scatter_events"] == ref_c["scatter_events"] and c["shadow_walks"] == ref_c["shadow_walks"] and c["paths"] == ref_c["paths"]
