@@ -17,7 +17,7 @@ CSRC = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
 LIB_PATH = Path(os.environ["SVR_HIP_LIB"]) if os.environ.get("SVR_HIP_LIB") else LIB_DIR / "libsvr_hip.so"
 
-HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_wavefront.hip", "svr_accel.hip", "svr_raycast.hip", "svr_host_io.hip", "svr_volume_prep.hip", "svr_selftest.hip", "svr_trace_tile_fast.hip", "svr_trace_lm.hip", "svr_trace_split.hip"]
+HIP_SOURCES = ["svr_api.hip", "svr_kernels.hip", "svr_trace_tile.hip", "svr_wavefront.hip", "svr_accel.hip", "svr_raycast.hip", "svr_host_io.hip", "svr_volume_prep.hip", "svr_selftest.hip", "svr_trace_tile_fast.hip", "svr_trace_lm.hip", "svr_trace_split.hip", "svr_trace_env.hip"]
 # svr_trace_tile_fast.hip (the opt-in fast-math build) includes svr_trace_tile.hip and is compiled WITHOUT the contract flags
 FAST_SOURCES = {"svr_trace_tile_fast.hip"}
 CONTRACT_FLAGS = {"-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"}

@@ -56,6 +56,8 @@ struct Texture {
     // bits live in global memory and are consulted for fetches in cells the coarse level cannot rule out
     uint16_t* mm_fine = nullptr;
     int fg_x = 0, fg_y = 0, fg_z = 0;
+    // environment map: sampling table of SVR_OPT_ENV_NEE (svr_kernels.hip launch_env_cdf), built with the texture
+    float* env_cdf = nullptr;
     // transfer function: prefix count of exactly-zero alphas of the padded table, and an edit counter
     uint32_t* zero_prefix = nullptr;
     uint64_t version = 0;
@@ -127,7 +129,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1, opt_nan_guard = 0, opt_macro_shift_min = 0, opt_split = 1;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1, opt_nan_guard = 0, opt_macro_shift_min = 0, opt_split = 1, opt_env_nee = 0;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -361,6 +363,7 @@ int add_lights_env(svr::DevScene& s)
         if (!te) return fail(-2, "cudaEnvironmentLight.tex (0x%llx) is not a live environment texture handle", (unsigned long long)g.env.tex);
         s.env = (const float*)te->data;
         s.env_w = te->nx; s.env_h = te->ny;
+        s.env_cdf = te->env_cdf;
     }
     s.env_default[0] = g.env.defaultRadiance.x; s.env_default[1] = g.env.defaultRadiance.y; s.env_default[2] = g.env.defaultRadiance.z;
     s.env_intensity = g.env.intensity;
@@ -654,7 +657,11 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         HIP_TRY(hipMemsetAsync(rp->hdrBuffer, 0, sizeof(float) * 3 * (size_t)s.imageW * s.imageH, g.stream));
     svr::LaunchCfg cfg;
     cfg.kernel = g.opt_kernel == svr::KERNEL_AUTO ? svr::KERNEL_TILE : g.opt_kernel;
-    if ((cfg.kernel == svr::KERNEL_TILE || cfg.kernel == svr::KERNEL_WAVEFRONT) && ensure_mask(s, g.vol, g.tf)) return g.err_code;
+    // OPT-IN importance sampling of the environment map (svr_trace_env.hip): where there is a map, the environment term is on and a bounce follows the
+    // first scatter event (the env sample of event k pairs with the escape term of bounce k + 1)
+    if (g.opt_env_nee && cfg.kernel == svr::KERNEL_TILE && s.env != nullptr && s.env_cdf != nullptr && s.env_on_escape && rp->traceDepth >= 2 && !g.opt_debug_stop)
+        cfg.kernel = svr::KERNEL_ENV_NEE;
+    if ((cfg.kernel == svr::KERNEL_TILE || cfg.kernel == svr::KERNEL_WAVEFRONT || cfg.kernel == svr::KERNEL_ENV_NEE) && ensure_mask(s, g.vol, g.tf)) return g.err_code;
     if (cfg.kernel == svr::KERNEL_WAVEFRONT) {
         if (rp->traceDepth > 15) return fail(-3, "the wavefront kernels support traceDepth <= 15 (got %u)", rp->traceDepth);
         if (ensure_queues(s.imageW, s.imageH)) return g.err_code;
@@ -799,6 +806,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
         }
         if (cfg.kernel == svr::KERNEL_WAVEFRONT)
             HIP_TRY(svr::launch_wavefront(s, w, cfg, set.planes, set.wf_counts, (uint32_t)g.queue_capacity, ts));
+        else if (cfg.kernel == svr::KERNEL_ENV_NEE) HIP_TRY(svr::launch_trace_env(s, w, cfg, ts));
         else if (cfg.kernel == svr::KERNEL_TILE) {
             if (w.queue != nullptr && g.queue_used) HIP_TRY(hipStreamWaitEvent(ts, g.queue_done, 0));
             HIP_TRY(launch_tile(w, ts));
@@ -964,6 +972,7 @@ void svr_shutdown(void)
         if (kv.second->mm) hipFree(kv.second->mm);
         if (kv.second->mm_fine) hipFree(kv.second->mm_fine);
         if (kv.second->zero_prefix) hipFree(kv.second->zero_prefix);
+        if (kv.second->env_cdf) hipFree(kv.second->env_cdf);
         delete kv.second;
     }
     g.textures.clear();
@@ -1186,7 +1195,18 @@ int svr_update_tf_texture(uint64_t handle, const float* rgba, int n, int src_is_
 
 uint64_t svr_create_env_texture(const float* rgba, int w, int h, int src_is_device)
 {
-    return create_float4_texture(TEX_ENV, rgba, w, h, src_is_device);
+    const uint64_t hd = create_float4_texture(TEX_ENV, rgba, w, h, src_is_device);
+    if (!hd) return 0;
+    // the sampling table of SVR_OPT_ENV_NEE (a luminance distribution over the texels), built on the device
+    Texture* t = find_tex(hd, TEX_ENV);
+    float* tmp = nullptr;
+    hipError_t e = hipMalloc((void**)&t->env_cdf, ((size_t)h * (w + 1) + h + 1) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&tmp, ((size_t)w * h + 1) * sizeof(float));
+    if (e == hipSuccess) e = svr::launch_env_cdf((const float*)t->data, w, h, t->env_cdf, tmp, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (tmp) hipFree(tmp);
+    if (e != hipSuccess) { svr_destroy_texture(hd); fail((int)e, "environment sampling table: %s", hipGetErrorName(e)); return 0; }
+    return hd;
 }
 
 int svr_destroy_texture(uint64_t handle)
@@ -1200,6 +1220,7 @@ int svr_destroy_texture(uint64_t handle)
     if (t->mm) hipFree(t->mm);
     if (t->mm_fine) hipFree(t->mm_fine);
     if (t->zero_prefix) hipFree(t->zero_prefix);
+    if (t->env_cdf) hipFree(t->env_cdf);
     if (g.mask_vol == handle || g.mask_tf == handle) g.mask_valid = false;
     t->magic = 0;
     delete t;
@@ -1533,6 +1554,7 @@ int svr_set_option(int key, int value)
     case SVR_OPT_SPLIT:
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_SPLIT: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_split = value; g.split_alloc_failed = false; return 0;
+    case SVR_OPT_ENV_NEE: g.opt_env_nee = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_NAN_GUARD: g.opt_nan_guard = value ? 1 : 0; return 0;
     case SVR_OPT_MACRO_SHIFT_MIN:
         if (value < 0 || value > 6) return fail(-6, "SVR_OPT_MACRO_SHIFT_MIN: bad value %d (0..6)", value);
@@ -1585,6 +1607,7 @@ int svr_get_option(int key)
     case SVR_OPT_POOL: return g.opt_pool;
     case SVR_OPT_TRIPS: return g.opt_trips;
     case SVR_OPT_SPLIT: return g.opt_split;
+    case SVR_OPT_ENV_NEE: return g.opt_env_nee;
     case SVR_OPT_NAN_GUARD: return g.opt_nan_guard;
     case SVR_OPT_MACRO_SHIFT_MIN: return g.opt_macro_shift_min;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;

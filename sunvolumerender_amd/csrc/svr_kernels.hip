@@ -586,6 +586,61 @@ hipError_t launch_resolve(const DevScene& s, const DevWork& w, hipStream_t st)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Sampling table of an environment map (SVR_OPT_ENV_NEE, svr_trace_env.hip): weight of texel (i, j) = the largest luminance among the texel
+// and its 8 wrap-neighbours (the bilinear lookup at any point of the texel's cell reads only those) x sin(theta of the row) + a floor of
+// 1e-3 of the mean, so that the density is positive wherever the lookup can be; cdf = h rows of w + 1 prefix sums, then h + 1 prefix sums
+// of the row totals.  Built once per map.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_env_weights(const float4* __restrict__ env, int w, int h, float* __restrict__ wgt, float* __restrict__ mean_acc)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    if (e < w * h) {
+        const int i = e % w, j = e / w;
+        float m = 0.f;
+        for (int dj = -1; dj <= 1; ++dj)
+            for (int di = -1; di <= 1; ++di) {
+                const int ii = (i + di + w) % w, jj = (j + dj + h) % h;
+                const float4 t = env[jj * w + ii];
+                const float lum = 0.2126f * t.x + 0.7152f * t.y + 0.0722f * t.z;
+                m = fmaxf(m, lum > 0.f ? lum : 0.f);              // (a NaN or negative texel counts as black)
+            }
+        v = m * __builtin_sinf(3.14159265358979f * ((float)j + 0.5f) / (float)h);
+        wgt[e] = v;
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(mean_acc, v);
+}
+__global__ __launch_bounds__(64) void k_env_rows(const float* __restrict__ wgt, int w, int h, const float* __restrict__ mean_acc, float* __restrict__ cdf)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= h) return;
+    const float fl = fmaxf(1e-3f * (*mean_acc) / ((float)w * (float)h), 1e-30f);
+    float* row = cdf + (size_t)j * (size_t)(w + 1);
+    float acc = 0.f;
+    row[0] = 0.f;
+    for (int i = 0; i < w; ++i) { acc += wgt[(size_t)j * w + i] + fl; row[i + 1] = acc; }
+}
+__global__ void k_env_marginal(int w, int h, float* __restrict__ cdf)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float* marg = cdf + (size_t)h * (size_t)(w + 1);
+    float acc = 0.f;
+    marg[0] = 0.f;
+    for (int j = 0; j < h; ++j) { acc += cdf[(size_t)j * (size_t)(w + 1) + w]; marg[j + 1] = acc; }
+}
+hipError_t launch_env_cdf(const float* env_rgba, int w, int h, float* cdf, float* tmp, hipStream_t st)
+{
+    // tmp: w * h + 1 floats (weights, then the sum)
+    hipError_t e = hipMemsetAsync(tmp + (size_t)w * h, 0, sizeof(float), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_env_weights, dim3((w * h + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float4*>(env_rgba), w, h, tmp, tmp + (size_t)w * h);
+    hipLaunchKernelGGL(k_env_rows, dim3((h + 63) / 64), dim3(64), 0, st, tmp, w, h, tmp + (size_t)w * h, cdf);
+    hipLaunchKernelGGL(k_env_marginal, dim3(1), dim3(1), 0, st, w, h, cdf);
+    return hipGetLastError();
+}
+
 hipError_t launch_tonemap(const DevScene& s, const DevWork& w, hipStream_t st)
 {
     if (w.n_items == 0) return hipSuccess;

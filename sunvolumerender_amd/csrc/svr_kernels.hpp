@@ -6,7 +6,7 @@
 
 namespace svr {
 
-enum { KERNEL_AUTO = 0, KERNEL_PIXEL = 1, KERNEL_TILE = 2, KERNEL_ULOOP = 3, KERNEL_WAVEFRONT = 4 };
+enum { KERNEL_AUTO = 0, KERNEL_PIXEL = 1, KERNEL_TILE = 2, KERNEL_ULOOP = 3, KERNEL_WAVEFRONT = 4, KERNEL_ENV_NEE = 5 /* internal: SVR_OPT_ENV_NEE */ };
 constexpr int WF_QUEUE_PLANES = 18;         // 2 ray queues + 1 hit queue, 6 float4 planes each
 constexpr uint32_t TICKET_SHARDS = 8;       // sharded work counters (one per XCD group), 128 B apart
 constexpr uint32_t TICKET_STRIDE = 32;      // in uint32 words
@@ -61,6 +61,10 @@ hipError_t launch_trace_tile(const DevScene& scene, const DevWork& work, const L
 // deeper paths as two kernels (svr_trace_split.hip): front half (primary walks, first events in place) -> chunks of records -> lane machine; radiance to the scratch slots
 hipError_t launch_trace_split(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
 uint64_t split_chunks_worst_case(uint64_t n_paths_padded, uint32_t waves);
+// OPT-IN importance sampling of the environment map (svr_trace_env.hip): straight-line paths with one env sample per scatter event, into the scratch slots
+hipError_t launch_trace_env(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
+// its sampling table: cdf = h * (w + 1) + h + 1 floats, tmp = w * h + 1 floats of scratch
+hipError_t launch_env_cdf(const float* env_rgba, int w, int h, float* cdf, float* tmp, hipStream_t stream);
 // OPT-IN local-majorant kernel (svr_trace_lm.hip): needs scene.empty_mask (class table) and scene.ray_skip; folding launches need work.pend
 hipError_t launch_trace_lm(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, hipStream_t stream);
 // wavefront kernels (svr_wavefront.hip): gen -> [walk -> shade] x depth over dense queues with ballot/prefix-sum

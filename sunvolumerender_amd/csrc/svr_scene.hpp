@@ -82,6 +82,9 @@ struct DevScene {
     DevLight lights[8];
     uint32_t trips;                // lane machine of the tile kernel (svr_lanes.hpp): walking lanes run five iterations per turn (SVR_OPT_TRIPS).  LAST, so that the layout
                                    // of everything else -- and with it the code of every kernel that does not read it -- stays what it was
+    // (appended behind it for the same reason) SVR_OPT_ENV_NEE, svr_trace_env.hip: the env map's sampling table -- env_h rows of env_w + 1 prefix sums of the
+    // texel weights, then env_h + 1 prefix sums of the row sums -- or null
+    const float* env_cdf;
 };
 
 // per-launch work description.  Tracing and accumulation are decoupled: the trace kernel writes the

@@ -115,17 +115,19 @@ SVR_DEV int lm_step(const DevScene& s, const LDS& L, const LmGrid& g, LmWalk& w,
     if (COUNT) c.ipre++;
     uint32_t cl;
     if (g.fine) {
-        const bool empty = (L.emask[(uint32_t)w.q >> 5] >> ((uint32_t)w.q & 31u)) & 1u;
+        // (the three table words are read together -- one LDS round trip per cell instead of two dependent ones)
         const uint32_t hq = (uint32_t)((w.ix >> 1) + (w.iy >> 1) * s.mc_hgx + (w.iz >> 1) * s.mc_hgxy);
+        const uint32_t ew = L.emask[(uint32_t)w.q >> 5], cw = L.cls[hq >> 3], dw = L.dist[hq >> 3];
+        const bool empty = (ew >> ((uint32_t)w.q & 31u)) & 1u;
         cl = 0u;
-        if (!empty) { cl = (L.cls[hq >> 3] >> ((hq & 7u) << 2)) & 15u; w.run = 0u; }
+        if (!empty) { cl = (cw >> ((hq & 7u) << 2)) & 15u; w.run = 0u; }
         else if (++w.run >= 3u) {
             // Empty space: no free path is spent, so the walk may LEAP.  Every macro-cell within Chebyshev distance dd - 1 of this
             // one is empty (distance field, svr_accel.hip): the ray may advance until its largest-axis displacement is dd - 1
             // cells (first_occupied's sphere tracing, svr_walk.hpp) and pick up the DDA in the cell it lands in.  Boundaries are
             // absolute, so where exactly a leap lands does not change what follows.  (Tried from the third empty cell in a row on:
             // the gaps between the cells of a surface are shorter than that.)
-            const uint32_t dd = (L.dist[hq >> 3] >> ((hq & 7u) << 2)) & 15u;
+            const uint32_t dd = (dw >> ((hq & 7u) << 2)) & 15u;
             if (dd >= 4u) {
                 const float inv = fmin_(__builtin_fabsf(w.rx), fmin_(__builtin_fabsf(w.ry), __builtin_fabsf(w.rz))) * 0.999f;      // 1 / largest |B|
                 const float tl = fma_((float)dd - 1.05f, inv, w.t);
@@ -388,11 +390,18 @@ SVR_DEV v3 trace_path_lm(const DevScene& s, const LDS& L_, uint32_t x, uint32_t 
 #endif
 constexpr uint32_t LM_BATCH = SVR_LM_BATCH;               // tasks per batch: <= LM_CAP ray records
 constexpr uint32_t LM_CAP = LM_BATCH * 64;
+// the record pool of traceDepth 1 takes 21 tasks: 21 x 3 channels = 63 of 64 lanes fold (16 tasks: 48 -- the fold is 11 % of the kernel on c3 / c5)
+#ifndef SVR_LM_BATCH1
+#define SVR_LM_BATCH1 21
+#endif
+constexpr uint32_t LM_BATCH1 = SVR_LM_BATCH1;
+constexpr uint32_t LM_CAP1 = LM_BATCH1 * 64;
+static_assert(LM_CAP1 <= 2048, "a record's path id has 11 bits");
 constexpr uint32_t LM_RAY_WORDS = 17;                     // o(3) d(3) rng(6) meta p0..p3
 constexpr uint32_t LM_HIT_WORDS = 14;                     // pt(3) wo(3) val rng(6) meta
-static_assert((LM_RAY_WORDS + LM_HIT_WORDS) * LM_CAP <= REC_WORDS * QUEUE_CAP, "the pool's records fit the wave's queue slice");
-static_assert(LM_BATCH <= QUEUE_TASKS, "pending-radiance rows");
-// meta: id (10 bits: task-in-batch << 6 | lane) | light or (nearest light + 1) << 12
+static_assert((LM_RAY_WORDS + LM_HIT_WORDS) * LM_CAP1 <= REC_WORDS * QUEUE_CAP, "the pool's records fit the wave's queue slice");
+static_assert(LM_BATCH <= QUEUE_TASKS && LM_BATCH1 <= QUEUE_TASKS, "pending-radiance rows");
+// meta: id (11 bits: task-in-batch << 6 | lane) | light or (nearest light + 1) << 12
 SVR_DEV uint32_t lm_meta(uint32_t id, uint32_t light) { return id | (light << 12); }
 
 template <int LAYOUT, bool COUNT, typename LDS>
@@ -414,7 +423,7 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
     uint32_t meta = 0u;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
     auto put = [&](v3 L) {
-        const uint32_t id = meta & 0x3ffu;
+        const uint32_t id = meta & 0x7ffu;
         float* p = pendL + (id >> 6) * (3u * 64u) + (id & 63u);
         p[0] = L.x; p[64] = L.y; p[128] = L.z;
         st = IDLE;
@@ -430,10 +439,10 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
                 const uint32_t i = next + lane_rank(idle);
                 if (st == IDLE && i < n) {
                     const uint32_t* r = R + i;
-                    o = rec_v3_load(r, LM_CAP); d = rec_v3_load(r + 3 * LM_CAP, LM_CAP);
-                    rec_rng_load(r + 6 * LM_CAP, LM_CAP, rng);
-                    meta = r[12 * LM_CAP];
-                    p0 = u2f(r[13 * LM_CAP]); p1 = u2f(r[14 * LM_CAP]); p2 = u2f(r[15 * LM_CAP]); p3 = u2f(r[16 * LM_CAP]);
+                    o = rec_v3_load(r, LM_CAP1); d = rec_v3_load(r + 3 * LM_CAP1, LM_CAP1);
+                    rec_rng_load(r + 6 * LM_CAP1, LM_CAP1, rng);
+                    meta = r[12 * LM_CAP1];
+                    p0 = u2f(r[13 * LM_CAP1]); p1 = u2f(r[14 * LM_CAP1]); p2 = u2f(r[15 * LM_CAP1]); p3 = u2f(r[16 * LM_CAP1]);
                     if (shadows) {
                         // transmittance (transmittance.h:10-17): to the box exit along the light direction
                         float sNear, sFar;
@@ -513,10 +522,10 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
                     const uint64_t mh = __ballot(to_hit);
                     if (to_hit) {
                         uint32_t* h = H + nH + lane_rank(mh);
-                        rec_v3_store(h, LM_CAP, o + d * wk.t); rec_v3_store(h + 3 * LM_CAP, LM_CAP, -d);
-                        h[6 * LM_CAP] = f2u(val);
-                        rec_rng_store(h + 7 * LM_CAP, LM_CAP, rng);
-                        h[13 * LM_CAP] = meta & 0x3ffu;
+                        rec_v3_store(h, LM_CAP1, o + d * wk.t); rec_v3_store(h + 3 * LM_CAP1, LM_CAP1, -d);
+                        h[6 * LM_CAP1] = f2u(val);
+                        rec_rng_store(h + 7 * LM_CAP1, LM_CAP1, rng);
+                        h[13 * LM_CAP1] = meta & 0x7ffu;
                         st = IDLE;
                     }
                     nH += (uint32_t)__popcll(mh);
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
     const size_t wslot = (size_t)(blockIdx.x * TILE_WAVES + wave);
     float* const gpend = w.pend + wslot * (QUEUE_TASKS * 3u * 64u);
     uint32_t* const R = w.queue + wslot * (REC_WORDS * QUEUE_CAP);       // ray records
-    uint32_t* const H = R + (size_t)LM_RAY_WORDS * LM_CAP;               // hit records
+    uint32_t* const H = R + (size_t)LM_RAY_WORDS * LM_CAP1;               // hit records
     Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     ProfLocal pl = {};
     auto fence = [&]() {
@@ -553,10 +562,10 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
     };
     uint32_t si = 0u;                                                     // ticket counters visited so far
     for (;;) {
-        // ---- gen: up to LM_BATCH tasks ----
+        // ---- gen: up to LM_BATCH1 tasks ----
         LPROF_BEGIN(pgen);
         uint32_t nb = 0u, nR = 0u;
-        while (nb < LM_BATCH && si < TICKET_SHARDS) {
+        while (nb < LM_BATCH1 && si < TICKET_SHARDS) {
             const uint32_t shard = (shard0 + si) % TICKET_SHARDS;
             uint32_t* ticket = w.ticket + shard * TICKET_STRIDE;
             // away from the home counter, look before taking (a plain load of a drained counter is free)
@@ -621,10 +630,10 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             const uint64_t mq = __ballot(queued);
             if (queued) {
                 uint32_t* rr = R + nR + lane_rank(mq);
-                rec_v3_store(rr, LM_CAP, orig); rec_v3_store(rr + 3 * LM_CAP, LM_CAP, dir);
-                rec_rng_store(rr + 6 * LM_CAP, LM_CAP, rng);
-                rr[12 * LM_CAP] = lm_meta((nb << 6) | lane, (uint32_t)(ls_id + 1));
-                rr[13 * LM_CAP] = f2u(ls_t); rr[14 * LM_CAP] = f2u(t0); rr[15 * LM_CAP] = f2u(tMax); rr[16 * LM_CAP] = 0u;
+                rec_v3_store(rr, LM_CAP1, orig); rec_v3_store(rr + 3 * LM_CAP1, LM_CAP1, dir);
+                rec_rng_store(rr + 6 * LM_CAP1, LM_CAP1, rng);
+                rr[12 * LM_CAP1] = lm_meta((nb << 6) | lane, (uint32_t)(ls_id + 1));
+                rr[13 * LM_CAP1] = f2u(ls_t); rr[14 * LM_CAP1] = f2u(t0); rr[15 * LM_CAP1] = f2u(tMax); rr[16 * LM_CAP1] = 0u;
             }
             nR += (uint32_t)__popcll(mq);
             if (lane == 0) pend_task[wave][nb] = k;
@@ -651,10 +660,10 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             uint32_t id = 0u;
             if (i < nH) {
                 const uint32_t* h = H + i;
-                vs.pt = rec_v3_load(h, LM_CAP); vs.wo = rec_v3_load(h + 3 * LM_CAP, LM_CAP);
-                const float val = u2f(h[6 * LM_CAP]);
-                rec_rng_load(h + 7 * LM_CAP, LM_CAP, rng);
-                id = h[13 * LM_CAP];
+                vs.pt = rec_v3_load(h, LM_CAP1); vs.wo = rec_v3_load(h + 3 * LM_CAP1, LM_CAP1);
+                const float val = u2f(h[6 * LM_CAP1]);
+                rec_rng_load(h + 7 * LM_CAP1, LM_CAP1, rng);
+                id = h[13 * LM_CAP1];
                 shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
                 have = ne.have;
                 if (!have) {                                                  // no light sample reaches the event: L = 0
@@ -665,10 +674,10 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             const uint64_t ms = __ballot(have);
             if (have) {
                 uint32_t* rr = R + nS + lane_rank(ms);                        // (the primary ray records have all been consumed)
-                rec_v3_store(rr, LM_CAP, vs.pt); rec_v3_store(rr + 3 * LM_CAP, LM_CAP, ne.wi);
-                rec_rng_store(rr + 6 * LM_CAP, LM_CAP, rng);
-                rr[12 * LM_CAP] = lm_meta(id, ne.light);
-                rr[13 * LM_CAP] = f2u(ne.B.x); rr[14 * LM_CAP] = f2u(ne.B.y); rr[15 * LM_CAP] = f2u(ne.B.z); rr[16 * LM_CAP] = f2u(ne.pdf);
+                rec_v3_store(rr, LM_CAP1, vs.pt); rec_v3_store(rr + 3 * LM_CAP1, LM_CAP1, ne.wi);
+                rec_rng_store(rr + 6 * LM_CAP1, LM_CAP1, rng);
+                rr[12 * LM_CAP1] = lm_meta(id, ne.light);
+                rr[13 * LM_CAP1] = f2u(ne.B.x); rr[14 * LM_CAP1] = f2u(ne.B.y); rr[15 * LM_CAP1] = f2u(ne.B.z); rr[16 * LM_CAP1] = f2u(ne.pdf);
             }
             nS += (uint32_t)__popcll(ms);
         }
