@@ -258,7 +258,8 @@ int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_loc
                                      * and pixel jitter included; conservative host-side test) are skipped by the primary rays' nearest-light test
                                      * (core/lights/light_sample.h:23-49).  Results unchanged */
 #define SVR_OPT_LM_TUNE 25          /* local-majorant pool kernel, speed only: macro-cells a walking lane may cross per turn | idle lanes that trigger a
-                                     * refill << 8 | ended walks that trigger their settling << 16 (each 1..64); 0 (default) = chosen per scene */
+                                     * refill << 8 | ended walks that trigger their settling << 16 (each 1..64) | tasks per batch of the traceDepth-1 pool << 24
+                                     * (0 = the default for the scene; < 16 selects the 10-task build, >= 16 the 21-task build); 0 (default) = everything chosen per scene */
 #define SVR_OPT_LM_SUBCELLS 26      /* local-majorant mode: a walk spends its free path only in the occupied eighths (2 x 2 x 2 fine cells) of a macro-cell --
                                      * fewer wasted tentative collisions where a surface cuts a cell.  0 off, 1 (default) where macro-cells are >= 16 voxels
                                      * (volumes beyond 512^3), 2 always.  Changes the random numbers a path

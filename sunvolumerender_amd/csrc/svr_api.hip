@@ -547,7 +547,9 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
     // pool tuning (same-box sweeps, gpurun_out/r03p_lm_tune.log): on the full-resolution grid (scenes with empty space) one cell per turn
     // (c3 9 920 / c5 8 430 Msamples/s against 9 480 / 7 630 with three), on the half-resolution grid of fog-like media three cells
     // and later refills (c3n 4 860 against 4 290 with one cell)
-    s.lm_tune = g.opt_lm_tune ? (uint32_t)g.opt_lm_tune : (g.mask_has_empty ? (1u | (16u << 8) | (16u << 16)) : (3u | (24u << 8) | (24u << 16)));
+    // tasks per batch of the traceDepth-1 pool (bits 24-31; same-box A/B, 10 / 16 / 21 tasks: c3 10 215 / 10 064 / 9 821, c5 8 611 / 8 383 / 8 173, c3n 4 747 / 4 932 / 4 972)
+    s.lm_tune = g.opt_lm_tune ? (uint32_t)g.opt_lm_tune : (g.mask_has_empty ? (1u | (16u << 8) | (16u << 16) | (10u << 24)) : (3u | (24u << 8) | (24u << 16) | (21u << 24)));
+    if ((s.lm_tune >> 24) == 0u) s.lm_tune |= (g.mask_has_empty ? 10u : 21u) << 24;
     // five-iteration trips of the lane machine: walks of tens of iterations with few fetches -- media without exactly transparent space under
     // bound culling (c3n: +20 %; c3 / c5 at depth 2: -1..2 %)
     s.trips = (g.opt_trips == 2 || (g.opt_trips == 1 && s.bound_cull && !s.has_empty)) ? 1u : 0u;
@@ -695,7 +697,7 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     // the slot-per-path pool of deeper paths settles its walks (slot loads and stores) and refills less eagerly: 2 cells per turn, a
     // refill from 32 idle lanes, settling from 48 ended walks (c3 depth 4: 3 390 Msamples/s against 2 630 with the depth-1 setting,
     // c3n depth 4: 1 080 against 810; gpurun_out/r03u_tune.log)
-    if (local_majorant && !g.opt_lm_tune && rp->traceDepth > 1) s.lm_tune = 2u | (32u << 8) | (48u << 16);
+    if (local_majorant && !g.opt_lm_tune && rp->traceDepth > 1) s.lm_tune = 2u | (32u << 8) | (48u << 16) | (s.lm_tune & 0xff000000u);
     if (local_majorant) use_queue = false;
     // POOL (svr_trace_tile.hip): pooled primary walks pay where the walks of a wave are not coherent -- media without exactly transparent
     // space under bound culling (c3n) -- and cost where they are (c3): auto = such media only
@@ -1528,8 +1530,8 @@ int svr_set_option(int key, int value)
         if (value < 0 || value > 2) return fail(-6, "SVR_OPT_LM_SUBCELLS: bad value %d (0 off, 1 auto, 2 always)", value);
         g.opt_lm_sub = value; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_LM_TUNE: {
-        const int steps = value & 0xff, refill = (value >> 8) & 0xff, ended = (value >> 16) & 0xff;
-        if (value != 0 && (steps < 1 || steps > 64 || refill < 1 || refill > 64 || ended < 1 || ended > 64)) return fail(-6, "SVR_OPT_LM_TUNE: bad value 0x%x (cells per turn | idle lanes << 8 | ended walks << 16, each 1..64)", value);
+        const int steps = value & 0xff, refill = (value >> 8) & 0xff, ended = (value >> 16) & 0xff, tasks = (value >> 24) & 0x7f;
+        if (value != 0 && (steps < 1 || steps > 64 || refill < 1 || refill > 64 || ended < 1 || ended > 64 || tasks > 23 || value < 0)) return fail(-6, "SVR_OPT_LM_TUNE: bad value 0x%x (cells per turn | idle lanes << 8 | ended walks << 16, each 1..64, | tasks per batch of the depth-1 pool << 24, 0 = default .. 23)", value);
         g.opt_lm_tune = value; return 0;
     }
     case SVR_OPT_LOCAL_MAJORANT:

@@ -117,7 +117,16 @@ SVR_DEV int lm_step(const DevScene& s, const LDS& L, const LmGrid& g, LmWalk& w,
     if (g.fine) {
         // (the three table words are read together -- one LDS round trip per cell instead of two dependent ones)
         const uint32_t hq = (uint32_t)((w.ix >> 1) + (w.iy >> 1) * s.mc_hgx + (w.iz >> 1) * s.mc_hgxy);
+#ifndef SVR_LM_LDS_TOGETHER
+#define SVR_LM_LDS_TOGETHER 0        // (reading the three table words up front -- one LDS round trip per cell instead of two dependent ones -- was 0.5 % SLOWER on c3 / c5)
+#endif
+#if SVR_LM_LDS_TOGETHER
         const uint32_t ew = L.emask[(uint32_t)w.q >> 5], cw = L.cls[hq >> 3], dw = L.dist[hq >> 3];
+#else
+        const uint32_t ew = L.emask[(uint32_t)w.q >> 5];
+#define cw L.cls[hq >> 3]
+#define dw L.dist[hq >> 3]
+#endif
         const bool empty = (ew >> ((uint32_t)w.q & 31u)) & 1u;
         cl = 0u;
         if (!empty) { cl = (cw >> ((hq & 7u) << 2)) & 15u; w.run = 0u; }
@@ -128,6 +137,10 @@ SVR_DEV int lm_step(const DevScene& s, const LDS& L, const LmGrid& g, LmWalk& w,
             // absolute, so where exactly a leap lands does not change what follows.  (Tried from the third empty cell in a row on:
             // the gaps between the cells of a surface are shorter than that.)
             const uint32_t dd = (dw >> ((hq & 7u) << 2)) & 15u;
+#if !SVR_LM_LDS_TOGETHER
+#undef cw
+#undef dw
+#endif
             if (dd >= 4u) {
                 const float inv = fmin_(__builtin_fabsf(w.rx), fmin_(__builtin_fabsf(w.ry), __builtin_fabsf(w.rz))) * 0.999f;      // 1 / largest |B|
                 const float tl = fma_((float)dd - 1.05f, inv, w.t);
@@ -390,9 +403,10 @@ SVR_DEV v3 trace_path_lm(const DevScene& s, const LDS& L_, uint32_t x, uint32_t 
 #endif
 constexpr uint32_t LM_BATCH = SVR_LM_BATCH;               // tasks per batch: <= LM_CAP ray records
 constexpr uint32_t LM_CAP = LM_BATCH * 64;
-// the record pool of traceDepth 1 takes 21 tasks: 21 x 3 channels = 63 of 64 lanes fold (16 tasks: 48 -- the fold is 11 % of the kernel on c3 / c5)
+// the record pool of traceDepth 1: up to 23 tasks per batch (the record memory of a wave); how many it takes is a run-time choice (DevScene.lm_tune bits 24-31:
+// scenes with transparent space do best with ~10 -- their records stay closer to the L2 --, fog with 21 = 63 of 64 lanes in the fold)
 #ifndef SVR_LM_BATCH1
-#define SVR_LM_BATCH1 21
+#define SVR_LM_BATCH1 23
 #endif
 constexpr uint32_t LM_BATCH1 = SVR_LM_BATCH1;
 constexpr uint32_t LM_CAP1 = LM_BATCH1 * 64;
@@ -404,10 +418,11 @@ static_assert(LM_BATCH <= QUEUE_TASKS && LM_BATCH1 <= QUEUE_TASKS, "pending-radi
 // meta: id (11 bits: task-in-batch << 6 | lane) | light or (nearest light + 1) << 12
 SVR_DEV uint32_t lm_meta(uint32_t id, uint32_t light) { return id | (light << 12); }
 
-template <int LAYOUT, bool COUNT, typename LDS>
+template <int LAYOUT, bool COUNT, uint32_t NB, typename LDS>
 SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, uint32_t n, const bool shadows, uint32_t* H, uint32_t& nH,
                           float* pendL, Cnt& c, ProfLocal& pl)
 {
+    constexpr uint32_t cap = NB * 64u;                                 // records per stage of a batch = the stride of a record's words
     enum : uint32_t { IDLE = 0u, WALK = 1u, TENT = 2u, END = 3u };
     const LmGrid g = lm_grid(s);
     const uint32_t steps_per_turn = s.lm_tune & 0xffu, refill_min = (s.lm_tune >> 8) & 0xffu, ended_min = (s.lm_tune >> 16) & 0xffu;
@@ -439,10 +454,10 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
                 const uint32_t i = next + lane_rank(idle);
                 if (st == IDLE && i < n) {
                     const uint32_t* r = R + i;
-                    o = rec_v3_load(r, LM_CAP1); d = rec_v3_load(r + 3 * LM_CAP1, LM_CAP1);
-                    rec_rng_load(r + 6 * LM_CAP1, LM_CAP1, rng);
-                    meta = r[12 * LM_CAP1];
-                    p0 = u2f(r[13 * LM_CAP1]); p1 = u2f(r[14 * LM_CAP1]); p2 = u2f(r[15 * LM_CAP1]); p3 = u2f(r[16 * LM_CAP1]);
+                    o = rec_v3_load(r, cap); d = rec_v3_load(r + 3 * cap, cap);
+                    rec_rng_load(r + 6 * cap, cap, rng);
+                    meta = r[12 * cap];
+                    p0 = u2f(r[13 * cap]); p1 = u2f(r[14 * cap]); p2 = u2f(r[15 * cap]); p3 = u2f(r[16 * cap]);
                     if (shadows) {
                         // transmittance (transmittance.h:10-17): to the box exit along the light direction
                         float sNear, sFar;
@@ -522,10 +537,10 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
                     const uint64_t mh = __ballot(to_hit);
                     if (to_hit) {
                         uint32_t* h = H + nH + lane_rank(mh);
-                        rec_v3_store(h, LM_CAP1, o + d * wk.t); rec_v3_store(h + 3 * LM_CAP1, LM_CAP1, -d);
-                        h[6 * LM_CAP1] = f2u(val);
-                        rec_rng_store(h + 7 * LM_CAP1, LM_CAP1, rng);
-                        h[13 * LM_CAP1] = meta & 0x7ffu;
+                        rec_v3_store(h, cap, o + d * wk.t); rec_v3_store(h + 3 * cap, cap, -d);
+                        h[6 * cap] = f2u(val);
+                        rec_rng_store(h + 7 * cap, cap, rng);
+                        h[13 * cap] = meta & 0x7ffu;
                         st = IDLE;
                     }
                     nH += (uint32_t)__popcll(mh);
@@ -536,9 +551,11 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
     }
 }
 
-template <int LAYOUT, bool COUNT>
+// NB: tasks per batch (compile time: the record stride NB x 64 sits in every address of the pool's loads and stores; as a run-time value it cost 1.4-5 %)
+template <int LAYOUT, bool COUNT, uint32_t NB>
 __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_pool(const DevScene s, const DevWork w)
 {
+    static_assert(NB >= 1 && NB <= LM_BATCH1, "tasks per batch");
     __shared__ LdsTileCull lds;
     __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
     __shared__ uint32_t pend_task[TILE_WAVES][QUEUE_TASKS];
@@ -553,7 +570,8 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
     const size_t wslot = (size_t)(blockIdx.x * TILE_WAVES + wave);
     float* const gpend = w.pend + wslot * (QUEUE_TASKS * 3u * 64u);
     uint32_t* const R = w.queue + wslot * (REC_WORDS * QUEUE_CAP);       // ray records
-    uint32_t* const H = R + (size_t)LM_RAY_WORDS * LM_CAP1;               // hit records
+    constexpr uint32_t batch_tasks = NB, cap = NB * 64u;
+    uint32_t* const H = R + (size_t)LM_RAY_WORDS * cap;                  // hit records
     Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     ProfLocal pl = {};
     auto fence = [&]() {
@@ -562,10 +580,10 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
     };
     uint32_t si = 0u;                                                     // ticket counters visited so far
     for (;;) {
-        // ---- gen: up to LM_BATCH1 tasks ----
+        // ---- gen: up to batch_tasks tasks ----
         LPROF_BEGIN(pgen);
         uint32_t nb = 0u, nR = 0u;
-        while (nb < LM_BATCH1 && si < TICKET_SHARDS) {
+        while (nb < batch_tasks && si < TICKET_SHARDS) {
             const uint32_t shard = (shard0 + si) % TICKET_SHARDS;
             uint32_t* ticket = w.ticket + shard * TICKET_STRIDE;
             // away from the home counter, look before taking (a plain load of a drained counter is free)
@@ -630,10 +648,10 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             const uint64_t mq = __ballot(queued);
             if (queued) {
                 uint32_t* rr = R + nR + lane_rank(mq);
-                rec_v3_store(rr, LM_CAP1, orig); rec_v3_store(rr + 3 * LM_CAP1, LM_CAP1, dir);
-                rec_rng_store(rr + 6 * LM_CAP1, LM_CAP1, rng);
-                rr[12 * LM_CAP1] = lm_meta((nb << 6) | lane, (uint32_t)(ls_id + 1));
-                rr[13 * LM_CAP1] = f2u(ls_t); rr[14 * LM_CAP1] = f2u(t0); rr[15 * LM_CAP1] = f2u(tMax); rr[16 * LM_CAP1] = 0u;
+                rec_v3_store(rr, cap, orig); rec_v3_store(rr + 3 * cap, cap, dir);
+                rec_rng_store(rr + 6 * cap, cap, rng);
+                rr[12 * cap] = lm_meta((nb << 6) | lane, (uint32_t)(ls_id + 1));
+                rr[13 * cap] = f2u(ls_t); rr[14 * cap] = f2u(t0); rr[15 * cap] = f2u(tMax); rr[16 * cap] = 0u;
             }
             nR += (uint32_t)__popcll(mq);
             if (lane == 0) pend_task[wave][nb] = k;
@@ -644,7 +662,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
         // ---- walk: primary rays ----
         uint32_t nH = 0u;
         fence();
-        lm_walk_pool<LAYOUT, COUNT>(s, lds, R, nR, false, H, nH, gpend, c, pl);
+        lm_walk_pool<LAYOUT, COUNT, NB>(s, lds, R, nR, false, H, nH, gpend, c, pl);
         fence();
         // ---- shade the collisions, 64 at a time: each becomes a shadow ray (or ends with L = 0) ----
         LPROF_BEGIN(psh);
@@ -660,10 +678,10 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             uint32_t id = 0u;
             if (i < nH) {
                 const uint32_t* h = H + i;
-                vs.pt = rec_v3_load(h, LM_CAP1); vs.wo = rec_v3_load(h + 3 * LM_CAP1, LM_CAP1);
-                const float val = u2f(h[6 * LM_CAP1]);
-                rec_rng_load(h + 7 * LM_CAP1, LM_CAP1, rng);
-                id = h[13 * LM_CAP1];
+                vs.pt = rec_v3_load(h, cap); vs.wo = rec_v3_load(h + 3 * cap, cap);
+                const float val = u2f(h[6 * cap]);
+                rec_rng_load(h + 7 * cap, cap, rng);
+                id = h[13 * cap];
                 shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
                 have = ne.have;
                 if (!have) {                                                  // no light sample reaches the event: L = 0
@@ -674,10 +692,10 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             const uint64_t ms = __ballot(have);
             if (have) {
                 uint32_t* rr = R + nS + lane_rank(ms);                        // (the primary ray records have all been consumed)
-                rec_v3_store(rr, LM_CAP1, vs.pt); rec_v3_store(rr + 3 * LM_CAP1, LM_CAP1, ne.wi);
-                rec_rng_store(rr + 6 * LM_CAP1, LM_CAP1, rng);
-                rr[12 * LM_CAP1] = lm_meta(id, ne.light);
-                rr[13 * LM_CAP1] = f2u(ne.B.x); rr[14 * LM_CAP1] = f2u(ne.B.y); rr[15 * LM_CAP1] = f2u(ne.B.z); rr[16 * LM_CAP1] = f2u(ne.pdf);
+                rec_v3_store(rr, cap, vs.pt); rec_v3_store(rr + 3 * cap, cap, ne.wi);
+                rec_rng_store(rr + 6 * cap, cap, rng);
+                rr[12 * cap] = lm_meta(id, ne.light);
+                rr[13 * cap] = f2u(ne.B.x); rr[14 * cap] = f2u(ne.B.y); rr[15 * cap] = f2u(ne.B.z); rr[16 * cap] = f2u(ne.pdf);
             }
             nS += (uint32_t)__popcll(ms);
         }
@@ -685,7 +703,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
         // ---- walk: shadow rays ----
         fence();
         uint32_t none = 0u;
-        lm_walk_pool<LAYOUT, COUNT>(s, lds, R, nS, true, H, none, gpend, c, pl);
+        lm_walk_pool<LAYOUT, COUNT, NB>(s, lds, R, nS, true, H, none, gpend, c, pl);
         fence();
         // ---- fold the batch ----
         LPROF_BEGIN(pfo);
@@ -1146,7 +1164,11 @@ static hipError_t launch_lm_t(const DevScene& s, const DevWork& w, const LaunchC
     hipError_t e = hipMemsetAsync(w.ticket, 0, sizeof(uint32_t) * TICKET_SHARDS * TICKET_STRIDE, st);
     if (e != hipSuccess) return e;
     // traceDepth 1 (the reference's default), folding launch, queue memory at hand: the pool form
-    if (w.traceDepth == 1u && w.fold && w.queue != nullptr && !cfg.lm_straight) hipLaunchKernelGGL((k_trace_lm_pool<LAYOUT, COUNT>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
+    if (w.traceDepth == 1u && w.fold && w.queue != nullptr && !cfg.lm_straight) {
+        // tasks per batch (DevScene.lm_tune bits 24-31): two builds -- 10 (scenes with transparent space) and 21 (fog: 63 of 64 lanes in the fold)
+        if (((s.lm_tune >> 24) & 0xffu) >= 16u) hipLaunchKernelGGL((k_trace_lm_pool<LAYOUT, COUNT, 21>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
+        else hipLaunchKernelGGL((k_trace_lm_pool<LAYOUT, COUNT, 10>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
+    }
     else if (w.traceDepth > 1u && w.fold && w.queue != nullptr && !cfg.lm_straight) hipLaunchKernelGGL((k_trace_lm_pool_deep<LAYOUT, COUNT>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
     else if (w.traceDepth == 1u) hipLaunchKernelGGL((k_trace_lm<LAYOUT, COUNT, true>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
     else hipLaunchKernelGGL((k_trace_lm<LAYOUT, COUNT, false>), dim3(blocks), dim3(LM_THREADS), 0, st, s, w2);
