@@ -62,31 +62,36 @@ struct Nee { v3 wi; v3 B; float pdf; uint32_t light; bool have; };
 
 // VolumeSample + the light sampling of estimate_direct_light (pathtracer.cu:237-257, 171-190) for the scatter event at
 // vs.pt / vs.wo with intensity val: fills vs and the estimate; what follows is the shadow walk along ne.wi
+// scp (here and in trace_primary / gen_primary / drain_queue): where to read the scene constants that only set-up, shading and settling use -- transfer
+// function, spacing, lights, camera, environment.  Null: from `s` like everything else.  The queue builds of the tile kernel pass a pointer into the kernarg
+// segment that the compiler cannot see through (svr_trace_tile.hip, cold_scene), so those ~60 constants are scalar-loaded where they are used instead of
+// staying in (spilled) scalar registers across the walk loops.
 template <int LAYOUT, bool COUNT>
-SVR_DEV void shade_event(const DevScene& s, Shade& vs, float val, Rng& rng, Nee& ne, Cnt& c)
+SVR_DEV void shade_event(const DevScene& s, Shade& vs, float val, Rng& rng, Nee& ne, Cnt& c, const DevScene* scp = nullptr)
 {
+    const DevScene& sc = scp ? *scp : s;
     if (COUNT) { c.scatter++; c.taps += 7; c.exec += 6; }
-    tf_rgba(s, s.tf, val, vs.color);
+    tf_rgba(sc, sc.tf, val, vs.color);
     {
         // Gradient_CentralDiff, cuda_volume.h:54-61
         const v3 q = vs.pt;
-        float xd = intensity_at<LAYOUT>(s, V3(q.x + s.spacing[0], q.y + 0.f, q.z + 0.f)) -
-                   intensity_at<LAYOUT>(s, V3(q.x - s.spacing[0], q.y - 0.f, q.z - 0.f));
-        float yd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + s.spacing[1], q.z + 0.f)) -
-                   intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - s.spacing[1], q.z - 0.f));
-        float zd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + 0.f, q.z + s.spacing[2])) -
-                   intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - 0.f, q.z - s.spacing[2]));
-        vs.gradient = V3((xd * 0.5f) * s.invSpacing[0], (yd * 0.5f) * s.invSpacing[1], (zd * 0.5f) * s.invSpacing[2]);
+        float xd = intensity_at<LAYOUT>(s, V3(q.x + sc.spacing[0], q.y + 0.f, q.z + 0.f)) -
+                   intensity_at<LAYOUT>(s, V3(q.x - sc.spacing[0], q.y - 0.f, q.z - 0.f));
+        float yd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + sc.spacing[1], q.z + 0.f)) -
+                   intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - sc.spacing[1], q.z - 0.f));
+        float zd = intensity_at<LAYOUT>(s, V3(q.x + 0.f, q.y + 0.f, q.z + sc.spacing[2])) -
+                   intensity_at<LAYOUT>(s, V3(q.x - 0.f, q.y - 0.f, q.z - sc.spacing[2]));
+        vs.gradient = V3((xd * 0.5f) * sc.invSpacing[0], (yd * 0.5f) * sc.invSpacing[1], (zd * 0.5f) * sc.invSpacing[2]);
     }
     const float gradMag = __builtin_sqrtf(dot(vs.gradient, vs.gradient));
-    vs.Pbrdf = vs.color[3] * (1.f - expf_(s.pbrdf_c * gradMag * 65535.f * s.invMaxMagnitude));
+    vs.Pbrdf = vs.color[3] * (1.f - expf_(sc.pbrdf_c * gradMag * 65535.f * sc.invMaxMagnitude));
     vs.st = (rng_uniform(rng) < vs.Pbrdf) ? 1 : 0;
     ne.have = false;
-    if (s.num_lights != 0) {
-        int li = (int)((float)s.num_lights * rng_uniform(rng));
-        li = li < (int)s.num_lights ? li : (int)s.num_lights - 1;
+    if (sc.num_lights != 0) {
+        int li = (int)((float)sc.num_lights * rng_uniform(rng));
+        li = li < (int)sc.num_lights ? li : (int)sc.num_lights - 1;
         v3 Li;
-        if (sample_light(s.lights[li], vs.pt, rng, ne.wi, ne.pdf, Li)) {
+        if (sample_light(sc.lights[li], vs.pt, rng, ne.wi, ne.pdf, Li)) {
             ne.have = true;
             ne.light = (uint32_t)li;
             ne.B = bsdf_eval(vs, ne.wi);
@@ -240,8 +245,10 @@ SVR_DEV void queue_push_a(const LaneQueue& Q, uint32_t& nA, bool live, const Sha
 // svr_trace_split.hip): straight to its scratch slot, found from the chunk's table tasks[id] = frame slot << 26 | pixel index.
 template <int LAYOUT, bool COUNT, bool SKIP, bool DEPTH1, typename LDS, bool POOL = false, bool HIT_B = false, int OUT = 0>
 SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, uint32_t nC, uint32_t nA, uint32_t nB0, uint32_t traceDepth_, float* pendL, uint32_t pend_row, Cnt& c,
-                         unsigned long long* c_prof = nullptr, const bool primary = false, uint32_t* nH = nullptr, const DevWork* wk = nullptr, const uint32_t* tasks = nullptr)
+                         unsigned long long* c_prof = nullptr, const bool primary = false, uint32_t* nH = nullptr, const DevWork* wk = nullptr, const uint32_t* tasks = nullptr,
+                         const DevScene* scp = nullptr)
 {
+    const DevScene& sc = scp ? *scp : s;
     enum : uint32_t { IDLE = 0u, CELL = 1u, WALK = 2u, FETCH = 3u, MARCH = 4u, END = 5u, WANT_A = 6u, WANT_B = 7u };
     const float INF = u2f(SVR_INF_BITS);
     const uint32_t traceDepth = DEPTH1 ? 1u : traceDepth_;
@@ -409,8 +416,8 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
         // transmittance.h:15-16 on the walk's result ts (t, or -FLT_MAX), with the box interval of the shadow ray
         const float ts = hit ? t : -SVR_FLT_MAX;
         const float Tr = ((ts > tMin) && (ts < tMax)) ? 0.f : 1.f;
-        const float kf = Tr * (float)s.num_lights;
-        const DevLight& l = s.lights[ne.light];
+        const float kf = Tr * (float)sc.num_lights;
+        const DevLight& l = sc.lights[ne.light];
         const v3 Li = V3(l.radiance[0], l.radiance[1], l.radiance[2]);     // sample_light returned true: cosTerm > 0
         L = L + T * (((ne.B * kf) * Li) / ne.pdf);
     };
@@ -452,12 +459,12 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
                     const float tt = hit ? t : SVR_FLT_MAX;
                     const uint32_t ls1 = ne.light;                          // nearest light + 1 (0 = none); ne.pdf holds its t
                     if (ls1 != 0u && ne.pdf < tt) {
-                        const DevLight& l = s.lights[ls1 - 1u];
+                        const DevLight& l = sc.lights[ls1 - 1u];
                         const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -dir);
                         L = L + (T * V3(l.radiance[0], l.radiance[1], l.radiance[2])) * (cosTerm <= 0.f ? 0.f : 1.f);
                         finish();
                     } else if (!hit) {
-                        if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+                        if (sc.env_on_escape) L = L + T * env_radiance(sc, dir);
                         finish();
                     } else to_hit = true;
                 }
@@ -534,7 +541,7 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
             ++k;
             begin_walk(false, false);                                       // the next bounce's walk (pathtracer.cu:218)
             if (st == END) {                                                // its result is known: no collision
-                if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+                if (sc.env_on_escape) L = L + T * env_radiance(sc, dir);
                 finish();
             }
         };
@@ -594,7 +601,7 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
             const uint64_t m = __ballot(st == WANT_B);
             if (m == 0ull) return;
             PROF_BEGIN(ps, PH_SHADE);
-            if (st == WANT_B) { shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c); after_shade(); }
+            if (st == WANT_B) { shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c, scp); after_shade(); }
             PROF_END(ps, (uint32_t)__popcll(m));
         };
         const uint32_t park_end = s.park_end;
@@ -637,7 +644,7 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
                         if (k + 1u >= traceDepth) finish();            // sample_bsdf / roulette of the last bounce cannot reach L
                         else st = WANT_A;
                     } else if (!hit) {                                  // pathtracer.cu:231-236
-                        if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+                        if (sc.env_on_escape) L = L + T * env_radiance(sc, dir);
                         finish();
                     } else {
                         vs.wo = -dir;

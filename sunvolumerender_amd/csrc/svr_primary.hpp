@@ -18,17 +18,18 @@ namespace svr {
 // svr_lanes.hpp continues the path -- and false if the path is over, with its radiance in L.
 template <int LAYOUT, bool COUNT, bool SKIP, typename LDS>
 SVR_DEV bool trace_primary(const DevScene& s, const LDS& L_, uint32_t x, uint32_t y, uint32_t hashed, bool group_march, uint32_t P2,
-                           GroupMapShared* gslot, Cnt& c, Rng& rng, v3& L, v3& pt, v3& wo, float& val)
+                           GroupMapShared* gslot, Cnt& c, Rng& rng, v3& L, v3& pt, v3& wo, float& val, const DevScene* scp = nullptr)
 {
-    uint32_t offset = y * s.imageW + x;
+    const DevScene& sc = scp ? *scp : s;                // (set-up constants: camera, lights, environment -- svr_lanes.hpp, shade_event)
+    uint32_t offset = y * sc.imageW + x;
     rng_init(rng, hashed + offset);
     if (COUNT) c.paths++;
     L = V3(0.f, 0.f, 0.f);
     const v3 T = V3(1.f, 1.f, 1.f);
     v3 orig, dir;
-    camera_ray(s, x, y, rng, orig, dir);
+    camera_ray(sc, x, y, rng, orig, dir);
     float ls_t;
-    int ls_id = nearest_light(s, orig, dir, ls_t);
+    int ls_id = nearest_light(sc, orig, dir, ls_t);
     float tMin = (float)1e-6, tMax = SVR_FLT_MAX;
     val = 0.f;
     float t;
@@ -44,14 +45,14 @@ SVR_DEV bool trace_primary(const DevScene& s, const LDS& L_, uint32_t x, uint32_
     if (ls_id >= 0) {
         float tt = t < 0.f ? SVR_FLT_MAX : t;
         if (ls_t < tt) {
-            const DevLight& l = s.lights[ls_id];
+            const DevLight& l = sc.lights[ls_id];
             float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -dir);
             L = L + (T * V3(l.radiance[0], l.radiance[1], l.radiance[2])) * (cosTerm <= 0.f ? 0.f : 1.f);
             return false;
         }
     }
     if (t < 0.f) {
-        if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+        if (sc.env_on_escape) L = L + T * env_radiance(sc, dir);
         return false;
     }
     wo = -dir;
@@ -63,15 +64,16 @@ SVR_DEV bool trace_primary(const DevScene& s, const LDS& L_, uint32_t x, uint32_
 // (orig / dir / tMin / tMax / t_occ / ls_* describe it: a P record, svr_lanes.hpp); false = the path is over with its radiance in L.
 template <bool COUNT, bool SKIP, typename LDS>
 SVR_DEV bool gen_primary(const DevScene& s, const LDS& L_, uint32_t x, uint32_t y, uint32_t hashed, bool group_march, uint32_t P2, GroupMapShared* gslot,
-                         Cnt& c, Rng& rng, v3& L, v3& orig, v3& dir, float& tMin, float& tMax, float& t_occ, float& ls_t, int& ls_id)
+                         Cnt& c, Rng& rng, v3& L, v3& orig, v3& dir, float& tMin, float& tMax, float& t_occ, float& ls_t, int& ls_id, const DevScene* scp = nullptr)
 {
-    uint32_t offset = y * s.imageW + x;
+    const DevScene& sc = scp ? *scp : s;
+    uint32_t offset = y * sc.imageW + x;
     rng_init(rng, hashed + offset);
     if (COUNT) c.paths++;
     L = V3(0.f, 0.f, 0.f);
     const v3 T = V3(1.f, 1.f, 1.f);
-    camera_ray(s, x, y, rng, orig, dir);
-    ls_id = nearest_light(s, orig, dir, ls_t);
+    camera_ray(sc, x, y, rng, orig, dir);
+    ls_id = nearest_light(sc, orig, dir, ls_t);
     tMin = (float)1e-6; tMax = SVR_FLT_MAX;
     int r;
     if (SKIP && group_march) {
@@ -83,12 +85,12 @@ SVR_DEV bool gen_primary(const DevScene& s, const LDS& L_, uint32_t x, uint32_t 
     if (r > 0) return true;
     // no walk: the result of sample_distance is -FLT_MAX (pathtracer.cu:220-235 with t < 0)
     if (ls_id >= 0) {
-        const DevLight& l = s.lights[ls_id];
+        const DevLight& l = sc.lights[ls_id];
         float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -dir);
         L = L + (T * V3(l.radiance[0], l.radiance[1], l.radiance[2])) * (cosTerm <= 0.f ? 0.f : 1.f);
         return false;
     }
-    if (s.env_on_escape) L = L + T * env_radiance(s, dir);
+    if (sc.env_on_escape) L = L + T * env_radiance(sc, dir);
     return false;
 }
 

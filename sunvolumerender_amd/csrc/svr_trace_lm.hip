@@ -420,9 +420,10 @@ SVR_DEV uint32_t lm_meta(uint32_t id, uint32_t light) { return id | (light << 12
 
 template <int LAYOUT, bool COUNT, uint32_t NB, typename LDS>
 SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, uint32_t n, const bool shadows, uint32_t* H, uint32_t& nH,
-                          float* pendL, Cnt& c, ProfLocal& pl)
+                          float* pendL, Cnt& c, ProfLocal& pl, const DevScene* scp = nullptr)
 {
     constexpr uint32_t cap = NB * 64u;                                 // records per stage of a batch = the stride of a record's words
+    const DevScene& sc = scp ? *scp : s;                               // (lights / environment of the settling: svr_lanes.hpp, shade_event)
     enum : uint32_t { IDLE = 0u, WALK = 1u, TENT = 2u, END = 3u };
     const LmGrid g = lm_grid(s);
     const uint32_t steps_per_turn = s.lm_tune & 0xffu, refill_min = (s.lm_tune >> 8) & 0xffu, ended_min = (s.lm_tune >> 16) & 0xffu;
@@ -516,8 +517,8 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
                         // estimate_direct_light's tail (pathtracer.cu:191-198): p0..p2 = bsdf, p3 = pdf
                         const float ts = hit ? wk.t : -SVR_FLT_MAX;
                         const float Tr = ((ts > tMin) && (ts < wk.tMax)) ? 0.f : 1.f;
-                        const float kf = Tr * (float)s.num_lights;
-                        const DevLight& l = s.lights[(meta >> 12) & 15u];
+                        const float kf = Tr * (float)sc.num_lights;
+                        const DevLight& l = sc.lights[(meta >> 12) & 15u];
                         put(((V3(p0, p1, p2) * kf) * V3(l.radiance[0], l.radiance[1], l.radiance[2])) / p3);
                     }
                 } else {
@@ -527,11 +528,11 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
                     if (st == END) {
                         const float tt = hit ? wk.t : SVR_FLT_MAX;
                         if (ls != 0u && p0 < tt) {
-                            const DevLight& l = s.lights[ls - 1u];
+                            const DevLight& l = sc.lights[ls - 1u];
                             const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -d);
                             put(V3(l.radiance[0], l.radiance[1], l.radiance[2]) * (cosTerm <= 0.f ? 0.f : 1.f));
                         } else if (!hit) {
-                            put(s.env_on_escape ? env_radiance(s, d) : V3(0.f, 0.f, 0.f));
+                            put(sc.env_on_escape ? env_radiance(sc, d) : V3(0.f, 0.f, 0.f));
                         } else to_hit = true;
                     }
                     const uint64_t mh = __ballot(to_hit);
@@ -571,6 +572,19 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
     float* const gpend = w.pend + wslot * (QUEUE_TASKS * 3u * 64u);
     uint32_t* const R = w.queue + wslot * (REC_WORDS * QUEUE_CAP);       // ray records
     constexpr uint32_t batch_tasks = NB, cap = NB * 64u;
+    // set-up / shading / settling constants through a laundered pointer into the kernarg segment (svr_trace_tile.hip, cold_scene)
+#ifndef SVR_LM_COLD_SCENE
+#define SVR_LM_COLD_SCENE 1
+#endif
+    auto cold_scene = [&]() -> const DevScene* {
+#if SVR_LM_COLD_SCENE
+        auto p = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return (const DevScene*)p;
+#else
+        return nullptr;
+#endif
+    };
     uint32_t* const H = R + (size_t)LM_RAY_WORDS * cap;                  // hit records
     Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     ProfLocal pl = {};
@@ -609,11 +623,13 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             float ls_t = 0.f, t0 = 0.f, tMax = 0.f;
             int ls_id = -1;
             if (live) {
+                const DevScene* scp = cold_scene();
+                const DevScene& sc = scp ? *scp : s;
                 const uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
-                rng_init(rng, wang_hash(w.frame0 + slot) + (y * s.imageW + x));
+                rng_init(rng, wang_hash(w.frame0 + slot) + (y * sc.imageW + x));
                 if (COUNT) c.paths++;
-                camera_ray(s, x, y, rng, orig, dir);
-                ls_id = nearest_light(s, orig, dir, ls_t);
+                camera_ray(sc, x, y, rng, orig, dir);
+                ls_id = nearest_light(sc, orig, dir, ls_t);
                 float tMin = (float)1e-6;
                 tMax = SVR_FLT_MAX;
                 bool run = false;
@@ -636,10 +652,10 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
                 }
                 if (run) queued = true;
                 else if (ls_id >= 0) {                                        // t = FLT_MAX > ls.t: the light is seen (pathtracer.cu:220-229)
-                    const DevLight& l = s.lights[ls_id];
+                    const DevLight& l = sc.lights[ls_id];
                     const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -dir);
                     L = V3(l.radiance[0], l.radiance[1], l.radiance[2]) * (cosTerm <= 0.f ? 0.f : 1.f);
-                } else if (s.env_on_escape) L = env_radiance(s, dir);
+                } else if (sc.env_on_escape) L = env_radiance(sc, dir);
             }
             {
                 float* p = gpend + (size_t)nb * (3u * 64u) + lane;           // (queued paths overwrite theirs when they end)
@@ -662,7 +678,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
         // ---- walk: primary rays ----
         uint32_t nH = 0u;
         fence();
-        lm_walk_pool<LAYOUT, COUNT, NB>(s, lds, R, nR, false, H, nH, gpend, c, pl);
+        lm_walk_pool<LAYOUT, COUNT, NB>(s, lds, R, nR, false, H, nH, gpend, c, pl, cold_scene());
         fence();
         // ---- shade the collisions, 64 at a time: each becomes a shadow ray (or ends with L = 0) ----
         LPROF_BEGIN(psh);
@@ -682,7 +698,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
                 const float val = u2f(h[6 * cap]);
                 rec_rng_load(h + 7 * cap, cap, rng);
                 id = h[13 * cap];
-                shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
+                shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c, cold_scene());
                 have = ne.have;
                 if (!have) {                                                  // no light sample reaches the event: L = 0
                     float* p = gpend + (id >> 6) * (3u * 64u) + (id & 63u);
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
         // ---- walk: shadow rays ----
         fence();
         uint32_t none = 0u;
-        lm_walk_pool<LAYOUT, COUNT, NB>(s, lds, R, nS, true, H, none, gpend, c, pl);
+        lm_walk_pool<LAYOUT, COUNT, NB>(s, lds, R, nS, true, H, none, gpend, c, pl, cold_scene());
         fence();
         // ---- fold the batch ----
         LPROF_BEGIN(pfo);

@@ -193,6 +193,22 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
+    // QUEUE builds: the scene constants that only set-up, shading and settling read (camera, lights, environment, transfer-function base, spacing: ~60 of
+    // the ~150 the kernel touches) are read through a pointer INTO THE KERNARG SEGMENT that is laundered per use, so the compiler scalar-loads them where
+    // they are used instead of keeping them in scalar registers -- i.e. in spilled ones: v_writelane / v_readlane -- across the walk loops
+    // (svr_lanes.hpp, shade_event).  DevScene is the kernel's first argument: offset 0 of the segment.
+#ifndef SVR_COLD_SCENE
+#define SVR_COLD_SCENE 1
+#endif
+    auto cold_scene = [&]() -> const DevScene* {
+        // (traceDepth-1 builds only: same-box A/B c3 9 690 against 9 500, c3n 2 381 / 2 351, c5 6 561 / 6 438; the deeper build LOSES 8 % with it --
+        // 4 508 against 4 884 at depth 2 -- its services settle walks one scalar load latency at a time)
+        if constexpr (QUEUE && DEPTH1 && SVR_COLD_SCENE) {
+            auto p = __builtin_amdgcn_kernarg_segment_ptr();          // (a pointer into the constant address space: the loads stay scalar)
+            asm volatile("" : "+s"(p));
+            return (const DevScene*)p;
+        } else return nullptr;
+    };
     // Lanes of a wave = (64 >> fl2) pixels x (1 << fl2) frames of the group: rays of one pixel in different frames
     // share origin, box segment and whole-ray test result up to sub-pixel jitter, so a wave is far more uniform
     // (skip / walk / hit, walk lengths) than 64 different pixels of one frame, and it touches fewer bricks.
@@ -227,14 +243,14 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 // deeper paths: qC camera rays (P records) -> collisions = B records (first scatter events, unshaded) of the machine below
                 static_assert(REC_C1_WORDS <= REC_A_WORDS, "P records lie in front of the B stack");
                 uint32_t nH = 0u;
-                drain_queue<LAYOUT, COUNT, SKIP, true, LDS, true, true, DIRECT>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH, &w, &pend.task[wave][0]);
+                drain_queue<LAYOUT, COUNT, SKIP, true, LDS, true, true, DIRECT>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH, &w, &pend.task[wave][0], cold_scene());
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 qC = 0u; qA = 0u; qB = nH;
             } else if constexpr (POOL) {
                 // qC camera rays (P records) -> collisions (H records) -> shaded, 64 at a time -> C1 records -> their shadow walks
                 uint32_t nH = 0u;
-                drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, true, false, DIRECT>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH, &w, &pend.task[wave][0]);
+                drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, true, false, DIRECT>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH, &w, &pend.task[wave][0], cold_scene());
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 qC = 0u;
@@ -253,7 +269,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                         const float val = u2f(h[6 * Q.cap]);
                         rec_rng_load(h + 7 * Q.cap, Q.cap, rng);
                         id = h[13 * Q.cap];
-                        shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
+                        shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c, cold_scene());
                         have = ne.have;
                         if (!have) {                                          // a first event no light sample reaches: L = 0
                             if constexpr (DIRECT) direct_put(s, w, &pend.task[wave][0], id, V3(0.f, 0.f, 0.f));
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, false, false, DIRECT>(s, lds, Q, qC, qA, qB, w.traceDepth, gpend, 64u, c, w.counters + CNT_N, false, nullptr, &w, &pend.task[wave][0]);
+            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, false, false, DIRECT>(s, lds, Q, qC, qA, qB, w.traceDepth, gpend, 64u, c, w.counters + CNT_N, false, nullptr, &w, &pend.task[wave][0], cold_scene());
             qC = qA = qB = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                     bool queued = false;
                     if (live) {
                         uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
-                        queued = gen_primary<COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, orig, dir, tMin, tMax, t_occ, ls_t, ls_id);
+                        queued = gen_primary<COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, orig, dir, tMin, tMax, t_occ, ls_t, ls_id, cold_scene());
                     }
                     {
                         const uint64_t m = __ballot(queued);
@@ -377,7 +393,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
 #endif
                     if (live) {
                         uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
-                        hit = trace_primary<LAYOUT, COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, vs.pt, vs.wo, val);
+                        hit = trace_primary<LAYOUT, COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, vs.pt, vs.wo, val, cold_scene());
                     }
                     PROF_END(pa, (uint32_t)__popcll(__ballot(live)));
 #if SVR_PROF
@@ -398,7 +414,8 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                         if (shade_here && mh != 0ull) {
                             PROF_BEGIN(psh, PH_SHADE);
                             if (hit) {
-                                shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
+                                const DevScene* scp = cold_scene();
+                                shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c, scp);
                                 if constexpr (!DEPTH1) {
                                     if (ne.have) {
                                         // estimate_direct_light, pathtracer.cu:191-198; the draws of sample_bsdf follow the
