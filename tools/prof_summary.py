@@ -12,7 +12,7 @@ out = sys.argv[1]
 
 def short(name):
     name = name.split("(")[0]
-    for k in ("k_trace_tile", "k_trace_lm", "k_pathtrace_uloop", "k_pathtrace_pixel", "k_resolve", "k_tonemap", "k_raycast", "k_repack",
+    for k in ("k_split_front", "k_split_machine", "k_trace_env", "k_trace_tile", "k_trace_lm", "k_pathtrace_uloop", "k_pathtrace_pixel", "k_resolve", "k_tonemap", "k_raycast", "k_repack",
               "k_minmax", "k_empty_mask"):
         if k in name:
             return k + ("<brick>" if ("ILi2E" in name or "<2," in name) else "<linear>" if ("ILi1E" in name or "<1," in name) else "")
@@ -38,7 +38,7 @@ for f in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.
             ndisp[k][c].add(row["Dispatch_Id"])
 print("## PMC counters, average per dispatch")
 for k in sorted(acc):
-    if not (k.startswith("k_pathtrace") or k.startswith("k_raycast") or k.startswith("k_trace")):
+    if not (k.startswith("k_pathtrace") or k.startswith("k_raycast") or k.startswith("k_trace") or k.startswith("k_split")):
         continue
     print(f"[{k}]")
     for c in sorted(acc[k]):
