@@ -51,6 +51,7 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0     # wave64 VALU instructions per ns: 2 cycles each on a SIMD-32 -> 1228.8 G/s
+GATHER_REQ_PEAK_G_S = 54.4                  # measured: random 16-byte gathers from a 2.2 GiB table, tools/ubench/gather16.hip (profiles/r04_fetch_size_calibration.txt)
 METRIC = "Msamples/sec (paths x spp) at 1024^2 on 512^3 volume"
 
 
@@ -171,11 +172,11 @@ def kernel_source_hash() -> str:
     return h()
 
 
-PMC_ROUND = "r03"
+PMC_ROUND = "r04"
 
 
 def pmc_record(tag: str, default_shape: bool = True):
-    """profiles/r03_pmc_<tag>.json: per-launch averages of the rocprofv3 --pmc passes of this workload (tools/pmc_json.py).
+    """profiles/r04_pmc_<tag>.json: per-launch averages of the rocprofv3 --pmc passes of this workload (tools/pmc_json.py).
     The records were taken at the default launch shape (64 frames per launch, automatic layout / queue / block count, no
     experiment option): a run with another shape gets no record, so its roofline fraction is null rather than wrong."""
     f = ROOT / "profiles" / f"{PMC_ROUND}_pmc_{tag}.json"
@@ -257,6 +258,12 @@ def roofline_block(counters, S, steps, k_ms, k_n, pmc):
                          "valu_insts_per_launch": int(pmc["valu_insts_per_launch"]),
                          "valu_peak_ginst_s": round(VALU_PEAK_GINST_S, 1),
                          "lane_utilisation": pmc.get("valu_lane_utilisation")})
+        if pmc.get("read_requests_per_launch"):
+            # the ceiling the software sampler's 16-byte gathers actually meet (profiles/r04_fetch_size_calibration.txt): ~54 G memory-side line
+            # requests per second, whatever part of the 128-byte line is used and whether the table lives in HBM or the Infinity Cache
+            rq = (pmc["read_requests_per_launch"] + pmc.get("WRITE_SIZE_KB_per_launch", 0.0) * 1024.0 / 128.0) / (avg_ms * 1e-3) / 1e9
+            roof.update({"mem_line_requests_g_per_s": round(rq, 2), "gather_request_peak_g_per_s": GATHER_REQ_PEAK_G_S,
+                         "gather_request_frac": round(rq / GATHER_REQ_PEAK_G_S, 4)})
         if pmc.get("traffic_bytes_per_launch"):
             t = pmc["traffic_bytes_per_launch"]
             roof.update({"traffic": int(t), "hbm_traffic_bytes": int(t), "hbm_peak_gbs": HBM_PEAK_GBS,
@@ -265,7 +272,7 @@ def roofline_block(counters, S, steps, k_ms, k_n, pmc):
 
 
 ROOF_HEAD = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_avg_ms", "lane_utilisation", "hbm_frac_traffic",
-             "executed_demand_frac", "pmc_source", "pmc_stale")
+             "gather_request_frac", "executed_demand_frac", "pmc_source", "pmc_stale")
 
 
 def compact_first(out: dict) -> dict:
@@ -484,6 +491,9 @@ def main():
             for d in (2, 4):
                 plan += [dict(tag=f"c3_depth{d}", scene="c3", depth=d, what=f"the headline scene at trace depth {d} (the reference's GUI range is 1-10)"),
                          dict(tag=f"c3_depth{d}_local_majorant", scene="c3", depth=d, lm=1, what=f"the headline scene at trace depth {d} " + LM_WHAT)]
+        if d0 == 1 and not args.fast_math:
+            plan += [dict(tag="c3_depth3_env_nee", scene="c3", depth=3, env_nee=1, what="the headline scene at trace depth 3 in the OPT-IN env-map importance sampling mode (SVR_OPT_ENV_NEE: "
+                                                                                         "one direction drawn from the map's luminance per scatter event + balance heuristic; straight-line paths)")]
         plan += [dict(tag="c3_noisy_air", scene="c3n", what="c3 with noisy non-zero air (64..191 raw LSB, like CT data rescaled to the full u16 range): no "
                                                             "macro-cell is exactly transparent"),
                  dict(tag="c3n_local_majorant", scene="c3n", lm=1, what="c3 with noisy non-zero air " + LM_WHAT)]
@@ -496,6 +506,7 @@ def main():
         for item in plan:
             tag, sc_name, what = item["tag"], item["scene"], item["what"]
             skip, fast, lm, depth = item.get("skip", 1), item.get("fast", 0), item.get("lm", 0), item.get("depth", d0)
+            env_nee = item.get("env_nee", 0)
             if sc_name != w2_scene:
                 if w2 is not wl:
                     w2.close()
@@ -503,9 +514,10 @@ def main():
             dev.set_option(abi.OPT_EMPTY_SKIP, skip)
             dev.set_option(abi.OPT_FAST_MATH, fast)
             dev.set_option(abi.OPT_LOCAL_MAJORANT, lm)
+            dev.set_option(abi.OPT_ENV_NEE, env_nee)
             w2.canvas.SetScatterTimes(depth)
             n = max(1, args.extra_steps)
-            c2 = None if (args.no_count or fast) else w2.count(n, S)
+            c2 = None if (args.no_count or fast or env_nee) else w2.count(n, S)
             w2.canvas.ReStartRender()
             w2.step(S)
             w2.canvas.ReStartRender()
@@ -519,15 +531,18 @@ def main():
             dt = time.perf_counter() - t1
             dev.set_option(abi.OPT_TIMING, 0)
             ms2, n2 = dev.kernel_time()
-            rec = None if fast else pmc_record(f"{sc_name}_d{depth}" + ("" if skip else "_noskip") + ("_lm" if lm else ""), default_shape)
+            rec = None if (fast or env_nee) else pmc_record(f"{sc_name}_d{depth}" + ("" if skip else "_noskip") + ("_lm" if lm else ""), default_shape)
             r2 = roofline_block(c2, S, n, ms2, n2, rec)
             if lm:
                 r2["kernel"] = "k_trace_lm"
+            elif depth >= 3 and sc_name != "c3n":
+                r2["kernel"] = "k_split_front + k_split_machine"       # (deeper paths as two kernels: `kernel_avg_ms` is the pair)
             extra[tag] = {"value": round(float(W) * H * S * n / dt / 1e6, 3), "unit": "Msamples/s", "steps": n,
                           "ms_per_step": round(dt / n * 1e3, 3), "trace_depth": depth, "what": what, "roofline": r2}
             dev.set_option(abi.OPT_EMPTY_SKIP, args.empty_skip)
             dev.set_option(abi.OPT_FAST_MATH, args.fast_math)
             dev.set_option(abi.OPT_LOCAL_MAJORANT, 0)
+            dev.set_option(abi.OPT_ENV_NEE, 0)
             w2.canvas.SetScatterTimes(d0)
         if w2 is not wl:
             w2.close()
