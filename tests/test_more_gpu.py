@@ -790,3 +790,31 @@ def test_split_kernels_bit_exact(hip_dev, name, depth):
             assert np.array_equal(img, ref_img)
             assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"]
             assert c["scatter_events"] == ref_c["scatter_events"] and c["shadow_walks"] == ref_c["shadow_walks"] and c["paths"] == ref_c["paths"]
+
+
+@pytest.mark.parametrize("case", ["window", "shard", "window_direct", "shard_direct"])
+def test_split_and_direct_builds_under_a_window_and_a_row_shard(hip_dev, case):
+    """The round-4 launch forms where pixels are not the whole frame: the two-kernel form of deeper paths (path ids = frame << 26 | GLOBAL pixel index)
+    and the DIRECT queue builds of frames traced ahead (a path writes its scratch slot itself), under a render window and under an interleaved row
+    shard; against the oracle on the owned pixels, untouched elsewhere."""
+    sc = scenes.make_scene("small_head", trace_depth=3 if "direct" not in case else 1)
+    kw = dict(window=(37, 50, 201, 190)) if "window" in case else dict(shard=(8, 2, 3))
+    frames = 72
+    ref_hdr, _, _ = oracle_frames(sc, frames, window=kw.get("window"))
+    hip_dev.set_option(abi.OPT_SPLIT, 2)
+    try:
+        # batch = one 72-frame call (a 64-frame and an 8-frame launch); per-frame calls = frames traced ahead (batches up to 64, DIRECT builds)
+        hdr, _, _ = hip_frames(hip_dev, sc, frames, batch="direct" not in case, count=False, **kw)
+    finally:
+        hip_dev.set_option(abi.OPT_SPLIT, 1)
+    if "window" in case:
+        x0, y0, x1, y1 = kw["window"]
+        assert_bit_exact(hdr[y0:y1, x0:x1], ref_hdr[y0:y1, x0:x1], case)
+        mask = np.ones(hdr.shape[:2], bool)
+        mask[y0:y1, x0:x1] = False
+        assert not hdr[mask].any()
+    else:
+        rows = dist.owned_rows(sc.height, *kw["shard"])
+        assert_bit_exact(hdr[rows], ref_hdr[rows], case)
+        other = np.setdiff1d(np.arange(sc.height), rows)
+        assert not hdr[other].any()
