@@ -918,15 +918,23 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
             HIP_TRY(hipEventRecord(set.resolved, g.stream));
             // steady state: a full batch takes as long to trace as to consume, so the NEXT one starts when this one is first used (it runs on
             // its set's stream beside the per-call resolves: the queue builds of the tile kernel leave the register room a resolve wave needs)
+            // (while the batches still grow -- 1, 2, 4 ... -- the next one, twice as long, is started the same way: the ramp's traces then run back to
+            // back instead of each waiting for its predecessor to be consumed; a host that restarts the render has at most two batches traced in vain)
             const uint32_t next_first = a.first + a.count;
-            if (a.count == batch_max && !in_stock(g.ahead[0], next_first) && !in_stock(g.ahead[1], next_first))
-                return trace_group(next_set(), next_first, batch_max, 0, false, ahead_queue);
+            const uint32_t next_count = 2u * a.count < batch_max ? 2u * a.count : batch_max;
+            if (next_count > 1u && !in_stock(g.ahead[0], next_first) && !in_stock(g.ahead[1], next_first))
+                return trace_group(next_set(), next_first, next_count, 0, false, ahead_queue && next_count >= 16u);
             return 0;
         }
         uint32_t batch = 1;
         while (batch < batch_max && 2u * batch <= n + 1u) batch *= 2u;
-        if (batch > 1 && ensure_slots(s.imageW, s.imageH, batch_max)) return g.err_code;
-        return trace_group(next_set(), n, batch, 1, want_img, ahead_queue && batch >= 16u);
+        if (batch_max > 1 && ensure_slots(s.imageW, s.imageH, batch_max)) return g.err_code;
+        if (trace_group(next_set(), n, batch, 1, want_img, ahead_queue && batch >= 16u)) return g.err_code;
+        if (batch_max > 1) {
+            const uint32_t next_count = 2u * batch < batch_max ? 2u * batch : batch_max;
+            return trace_group(next_set(), n + batch, next_count, 0, false, ahead_queue && next_count >= 16u);
+        }
+        return 0;
     }
 
     // folding launches may take 64 frames (a wave = ONE pixel x 64 frames): half as many launch boundaries
