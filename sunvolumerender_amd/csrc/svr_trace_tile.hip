@@ -189,6 +189,19 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
     __shared__ LDS lds;
     __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
     __shared__ typename std::conditional<QUEUE, LdsPendQueue, LdsPend>::type pend;
+    // QUEUE builds: the lights in LDS -- light sampling and the settling of a shadow walk index them PER LANE (a vector load from the kernarg
+    // segment otherwise: a dependent memory round trip in every settling round of the lane machine)
+#ifndef SVR_LDS_LIGHTS
+#define SVR_LDS_LIGHTS 1
+#endif
+    __shared__ DevLight lds_lights[QUEUE && DEPTH1 && SVR_LDS_LIGHTS ? 8 : 1];
+    if constexpr (QUEUE && DEPTH1 && SVR_LDS_LIGHTS) {
+        if (threadIdx.x < 8u * (sizeof(DevLight) / 4u))
+            reinterpret_cast<float*>(lds_lights)[threadIdx.x] = reinterpret_cast<const float*>(s.lights)[threadIdx.x];
+    }
+    // (traceDepth-1 builds: same-box A/B c3 9 626-9 805 against 9 522-9 526, c3n 2 403 / 2 386, c5 6 549 / 6 489; the deeper build loses 2.5 % with it)
+    constexpr bool LDSL = QUEUE && DEPTH1 && SVR_LDS_LIGHTS;
+    const DevLight* const lts = lds_lights;
     lds_tile_load(lds, s, SKIP);
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -243,14 +256,14 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 // deeper paths: qC camera rays (P records) -> collisions = B records (first scatter events, unshaded) of the machine below
                 static_assert(REC_C1_WORDS <= REC_A_WORDS, "P records lie in front of the B stack");
                 uint32_t nH = 0u;
-                drain_queue<LAYOUT, COUNT, SKIP, true, LDS, true, true, DIRECT>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH, &w, &pend.task[wave][0], cold_scene());
+                drain_queue<LAYOUT, COUNT, SKIP, true, LDS, true, true, DIRECT, LDSL>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH, &w, &pend.task[wave][0], cold_scene(), lts);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 qC = 0u; qA = 0u; qB = nH;
             } else if constexpr (POOL) {
                 // qC camera rays (P records) -> collisions (H records) -> shaded, 64 at a time -> C1 records -> their shadow walks
                 uint32_t nH = 0u;
-                drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, true, false, DIRECT>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH, &w, &pend.task[wave][0], cold_scene());
+                drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, true, false, DIRECT, LDSL>(s, lds, Q, qC, 0u, 0u, 1u, gpend, 64u, c, w.counters + CNT_N, true, &nH, &w, &pend.task[wave][0], cold_scene(), lts);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 qC = 0u;
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                         const float val = u2f(h[6 * Q.cap]);
                         rec_rng_load(h + 7 * Q.cap, Q.cap, rng);
                         id = h[13 * Q.cap];
-                        shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c, cold_scene());
+                        shade_event<LAYOUT, COUNT, LDSL>(s, vs, val, rng, ne, c, cold_scene(), lts);
                         have = ne.have;
                         if (!have) {                                          // a first event no light sample reaches: L = 0
                             if constexpr (DIRECT) direct_put(s, w, &pend.task[wave][0], id, V3(0.f, 0.f, 0.f));
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, false, false, DIRECT>(s, lds, Q, qC, qA, qB, w.traceDepth, gpend, 64u, c, w.counters + CNT_N, false, nullptr, &w, &pend.task[wave][0], cold_scene());
+            drain_queue<LAYOUT, COUNT, SKIP, DEPTH1, LDS, false, false, DIRECT, LDSL>(s, lds, Q, qC, qA, qB, w.traceDepth, gpend, 64u, c, w.counters + CNT_N, false, nullptr, &w, &pend.task[wave][0], cold_scene(), lts);
             qC = qA = qB = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -415,7 +428,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                             PROF_BEGIN(psh, PH_SHADE);
                             if (hit) {
                                 const DevScene* scp = cold_scene();
-                                shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c, scp);
+                                shade_event<LAYOUT, COUNT, LDSL>(s, vs, val, rng, ne, c, scp, lts);
                                 if constexpr (!DEPTH1) {
                                     if (ne.have) {
                                         // estimate_direct_light, pathtracer.cu:191-198; the draws of sample_bsdf follow the
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
                                         const float ts = walk<LAYOUT, COUNT, SKIP, SVR_SHADOW_REMARCH>(s, lds, vs.pt, ne.wi, rng, sMin, sMax, sval, true, c);
                                         const float Tr = ((ts > sMin) && (ts < sMax)) ? 0.f : 1.f;          // transmittance.h:15-16
                                         const float kf = Tr * (float)s.num_lights;
-                                        const DevLight& l = s.lights[ne.light];
+                                        const DevLight& l = LDSL ? lts[ne.light] : s.lights[ne.light];
                                         L = L + V3(1.f, 1.f, 1.f) * (((ne.B * kf) * V3(l.radiance[0], l.radiance[1], l.radiance[2])) / ne.pdf);
                                     }
                                 }
