@@ -26,6 +26,10 @@
 #include "svr_lanes.hpp"
 #include "svr_tile_tasks.hpp"
 
+#ifndef SVR_LM_LDS_LIGHTS
+#define SVR_LM_LDS_LIGHTS 1          // the depth-1 pool reads the lights from a copy in LDS (light sampling and settling index them per lane)
+#endif
+
 namespace svr {
 
 // bound of a class relative to sigma_max, and its reciprocal: b = min(bound_thr(c), 1) = 2^((c - 15) / 2) (svr_accel.hip)
@@ -420,10 +424,11 @@ SVR_DEV uint32_t lm_meta(uint32_t id, uint32_t light) { return id | (light << 12
 
 template <int LAYOUT, bool COUNT, uint32_t NB, typename LDS>
 SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, uint32_t n, const bool shadows, uint32_t* H, uint32_t& nH,
-                          float* pendL, Cnt& c, ProfLocal& pl, const DevScene* scp = nullptr)
+                          float* pendL, Cnt& c, ProfLocal& pl, const DevScene* scp = nullptr, const DevLight* lts = nullptr)
 {
     constexpr uint32_t cap = NB * 64u;                                 // records per stage of a batch = the stride of a record's words
     const DevScene& sc = scp ? *scp : s;                               // (lights / environment of the settling: svr_lanes.hpp, shade_event)
+    const DevLight* const LT = SVR_LM_LDS_LIGHTS ? lts : sc.lights;   // (the kernel's copy of the lights in LDS: indexed per lane)
     enum : uint32_t { IDLE = 0u, WALK = 1u, TENT = 2u, END = 3u };
     const LmGrid g = lm_grid(s);
     const uint32_t steps_per_turn = s.lm_tune & 0xffu, refill_min = (s.lm_tune >> 8) & 0xffu, ended_min = (s.lm_tune >> 16) & 0xffu;
@@ -518,7 +523,7 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
                         const float ts = hit ? wk.t : -SVR_FLT_MAX;
                         const float Tr = ((ts > tMin) && (ts < wk.tMax)) ? 0.f : 1.f;
                         const float kf = Tr * (float)sc.num_lights;
-                        const DevLight& l = sc.lights[(meta >> 12) & 15u];
+                        const DevLight& l = LT[(meta >> 12) & 15u];
                         put(((V3(p0, p1, p2) * kf) * V3(l.radiance[0], l.radiance[1], l.radiance[2])) / p3);
                     }
                 } else {
@@ -528,7 +533,7 @@ SVR_DEV void lm_walk_pool(const DevScene& s, const LDS& L_, const uint32_t* R, u
                     if (st == END) {
                         const float tt = hit ? wk.t : SVR_FLT_MAX;
                         if (ls != 0u && p0 < tt) {
-                            const DevLight& l = sc.lights[ls - 1u];
+                            const DevLight& l = LT[ls - 1u];
                             const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -d);
                             put(V3(l.radiance[0], l.radiance[1], l.radiance[2]) * (cosTerm <= 0.f ? 0.f : 1.f));
                         } else if (!hit) {
@@ -560,6 +565,9 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
     __shared__ LdsTileCull lds;
     __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
     __shared__ uint32_t pend_task[TILE_WAVES][QUEUE_TASKS];
+    __shared__ DevLight lds_lights[8];                                   // (light sampling and settling index the lights per lane: svr_trace_tile.hip)
+    if (threadIdx.x < 8u * (sizeof(DevLight) / 4u)) reinterpret_cast<float*>(lds_lights)[threadIdx.x] = reinterpret_cast<const float*>(s.lights)[threadIdx.x];
+    const DevLight* const lts = lds_lights;
     lds_tile_load(lds, s, true);
 
     const float INF = u2f(SVR_INF_BITS);
@@ -678,7 +686,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
         // ---- walk: primary rays ----
         uint32_t nH = 0u;
         fence();
-        lm_walk_pool<LAYOUT, COUNT, NB>(s, lds, R, nR, false, H, nH, gpend, c, pl, cold_scene());
+        lm_walk_pool<LAYOUT, COUNT, NB>(s, lds, R, nR, false, H, nH, gpend, c, pl, cold_scene(), lts);
         fence();
         // ---- shade the collisions, 64 at a time: each becomes a shadow ray (or ends with L = 0) ----
         LPROF_BEGIN(psh);
@@ -698,7 +706,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
                 const float val = u2f(h[6 * cap]);
                 rec_rng_load(h + 7 * cap, cap, rng);
                 id = h[13 * cap];
-                shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c, cold_scene());
+                shade_event<LAYOUT, COUNT, SVR_LM_LDS_LIGHTS != 0>(s, vs, val, rng, ne, c, cold_scene(), lts);
                 have = ne.have;
                 if (!have) {                                                  // no light sample reaches the event: L = 0
                     float* p = gpend + (id >> 6) * (3u * 64u) + (id & 63u);
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
         // ---- walk: shadow rays ----
         fence();
         uint32_t none = 0u;
-        lm_walk_pool<LAYOUT, COUNT, NB>(s, lds, R, nS, true, H, none, gpend, c, pl, cold_scene());
+        lm_walk_pool<LAYOUT, COUNT, NB>(s, lds, R, nS, true, H, none, gpend, c, pl, cold_scene(), lts);
         fence();
         // ---- fold the batch ----
         LPROF_BEGIN(pfo);
