@@ -34,6 +34,23 @@ __global__ __launch_bounds__(SPLIT_THREADS, 4) void k_split_front(const DevScene
     using LDS = typename std::conditional<SKIP, LdsTileCull, LdsTileNoMask>::type;
     __shared__ LDS lds;
     __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
+    // the front half is the tile kernel's traceDepth-1 front half: its set-up / shading constants through the laundered kernarg pointer and its
+    // lights in LDS (svr_trace_tile.hip, cold_scene / lds_lights)
+#ifndef SVR_SPLIT_COLD
+#define SVR_SPLIT_COLD 1
+#endif
+    __shared__ DevLight lds_lights[8];
+    if (threadIdx.x < 8u * (sizeof(DevLight) / 4u)) reinterpret_cast<float*>(lds_lights)[threadIdx.x] = reinterpret_cast<const float*>(s.lights)[threadIdx.x];
+    const DevLight* const lts = lds_lights;
+    auto cold_scene = [&]() -> const DevScene* {
+#if SVR_SPLIT_COLD
+        auto p = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return (const DevScene*)p;
+#else
+        return nullptr;
+#endif
+    };
     lds_tile_load(lds, s, SKIP);
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -83,21 +100,21 @@ __global__ __launch_bounds__(SPLIT_THREADS, 4) void k_split_front(const DevScene
             if (live) {
                 const uint32_t x = w.x0 + px, y = owned_row_to_y(w, r);
                 pix = y * s.imageW + x;
-                hit = trace_primary<LAYOUT, COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, vs.pt, vs.wo, val);
+                hit = trace_primary<LAYOUT, COUNT, SKIP>(s, lds, x, y, wang_hash(w.frame0 + slot), group_march, P2, &gmaps[wave][0], c, rng, L, vs.pt, vs.wo, val, cold_scene());
             }
             // the first scatter events are shaded in place and their shadow walks run in place (the lanes are frames of the same pixels).  Handing the
             // shaded events to the machine for their shadow walks instead (S records: an A record + the prepared estimate) was measured and lost:
             // c3 depth 2 / 4 3 776 / 2 427 against 4 750 / 3 029 Msamples/s (profiles/r04_notes_experiments.txt)
             if (shade_here && __ballot(hit) != 0ull) {
                 if (hit) {
-                    shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
+                    shade_event<LAYOUT, COUNT, SVR_SPLIT_COLD != 0>(s, vs, val, rng, ne, c, cold_scene(), lts);
                     if (ne.have) {
                         // estimate_direct_light, pathtracer.cu:191-198; the draws of sample_bsdf follow the shadow walk, so it consumes every draw up to the box exit
                         float sMin = (float)1e-6, sMax = SVR_FLT_MAX, sval = 0.f;
                         const float tsh = walk<LAYOUT, COUNT, SKIP, SVR_SHADOW_REMARCH>(s, lds, vs.pt, ne.wi, rng, sMin, sMax, sval, true, c);
                         const float Tr = ((tsh > sMin) && (tsh < sMax)) ? 0.f : 1.f;          // transmittance.h:15-16
                         const float kf = Tr * (float)s.num_lights;
-                        const DevLight& l = s.lights[ne.light];
+                        const DevLight& l = SVR_SPLIT_COLD ? lts[ne.light] : s.lights[ne.light];
                         L = L + V3(1.f, 1.f, 1.f) * (((ne.B * kf) * V3(l.radiance[0], l.radiance[1], l.radiance[2])) / ne.pdf);
                     }
                 }
