@@ -713,9 +713,8 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     // index, and the device has room for the worst-case record pool of a launch (<= 24 GB; else the fused kernel)
     bool use_split = false;
     const uint32_t split_group = (uint32_t)g.opt_group_frames;
-    // (same-box A/B, c3: depth 2 4 750 against the fused kernel's 4 884 Msamples/s, depth 4 3 029 against 2 978, depth 6 2 745 against 2 699: the scratch
-    // slots and the second launch cost ~0.4 ms per 64 frames, which the machine's own register budget wins back from three bounces on -> auto = depth >= 3)
-    if (g.opt_split && use_queue && rp->traceDepth >= (g.opt_split == 2 ? 2u : 3u) && rp->traceDepth < 32768u && !cfg.pool_primary && !local_majorant && !g.opt_fast_math && nframes >= 8 &&
+    // (same-box A/B, c3, two kernels / fused: depth 2 5 025 / 4 880, depth 3 3 745 / 3 555, depth 4 3 164 / 2 990, depth 6 2 800+ / 2 690: from depth 2 on)
+    if (g.opt_split && use_queue && rp->traceDepth >= 2u && rp->traceDepth < 32768u && !cfg.pool_primary && !local_majorant && !g.opt_fast_math && nframes >= 8 &&
         s.layout != svr::LAYOUT_LINEAR && (uint64_t)s.imageW * s.imageH <= (1ull << 26) && !frame_ahead_possible) {
         svr::DevWork wq;
         fill_work(wq, s.imageW, s.imageH);
@@ -1562,7 +1561,7 @@ int svr_set_option(int key, int value)
         if (value < 1 || value > 64) return fail(-6, "SVR_OPT_PARK_END: bad value %d (1..64)", value);
         g.opt_park_end = value; return 0;
     case SVR_OPT_SPLIT:
-        if (value < 0 || value > 2) return fail(-6, "SVR_OPT_SPLIT: bad value %d (0 off, 1 auto, 2 always)", value);
+        if (value < 0 || value > 2) return fail(-6, "SVR_OPT_SPLIT: bad value %d (0 off, 1 or 2 on)", value);
         g.opt_split = value; g.split_alloc_failed = false; return 0;
     case SVR_OPT_ENV_NEE: g.opt_env_nee = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_NAN_GUARD: g.opt_nan_guard = value ? 1 : 0; return 0;

@@ -149,6 +149,26 @@ __global__ __launch_bounds__(SPLIT_THREADS, 4) void k_split_machine(const DevSce
 {
     using LDS = typename std::conditional<SKIP, LdsTileCull, LdsTileNoMask>::type;
     __shared__ LDS lds;
+    // the machine, too, settles and shades with its lights in LDS and its constants through the laundered kernarg pointer: same-box A/B depth 2 / 3 / 4
+    // 5 025 / 3 745 / 3 164 against 4 931 / 3 655 / 3 088 (LDS lights alone: 4 940 / 3 669 / 3 101).  (The FUSED deeper kernel loses with either: svr_trace_tile.hip.)
+#ifndef SVR_SPLIT_MACHINE_COLD
+#define SVR_SPLIT_MACHINE_COLD 1
+#endif
+#ifndef SVR_SPLIT_MACHINE_LDSL
+#define SVR_SPLIT_MACHINE_LDSL 1
+#endif
+    __shared__ DevLight lds_lights[8];
+    if (threadIdx.x < 8u * (sizeof(DevLight) / 4u)) reinterpret_cast<float*>(lds_lights)[threadIdx.x] = reinterpret_cast<const float*>(s.lights)[threadIdx.x];
+    const DevLight* const lts = lds_lights;
+    auto cold_scene = [&]() -> const DevScene* {
+#if SVR_SPLIT_MACHINE_COLD
+        auto p = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return (const DevScene*)p;
+#else
+        return nullptr;
+#endif
+    };
     lds_tile_load(lds, s, SKIP);
     const uint32_t lane = threadIdx.x & 63u;
     Cnt c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -165,7 +185,8 @@ __global__ __launch_bounds__(SPLIT_THREADS, 4) void k_split_machine(const DevSce
         const uint32_t* cc = chunk_counts(w, chunk);
         const uint32_t nA = __builtin_amdgcn_readfirstlane(cc[0]), nB = __builtin_amdgcn_readfirstlane(cc[1]);
         if (COUNT) c.loops += (lane == 0);
-        drain_queue<LAYOUT, COUNT, SKIP, false, LDS, false, false, 2>(s, lds, Q, 0u, nA, nB, w.traceDepth, nullptr, 64u, c, w.counters + CNT_N, false, nullptr, &w, chunk_gids(w, chunk));
+        drain_queue<LAYOUT, COUNT, SKIP, false, LDS, false, false, 2, SVR_SPLIT_MACHINE_LDSL != 0>(s, lds, Q, 0u, nA, nB, w.traceDepth, nullptr, 64u, c, w.counters + CNT_N, false, nullptr, &w, chunk_gids(w, chunk),
+                                                                                                     cold_scene(), lts);
         // (records a later chunk's machine writes must not be read by this wave's earlier loads: the queue memory is per chunk, nothing to fence)
     }
     if (COUNT) cnt_flush(w, c);
