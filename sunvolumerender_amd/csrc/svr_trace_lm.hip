@@ -26,6 +26,9 @@
 #include "svr_lanes.hpp"
 #include "svr_tile_tasks.hpp"
 
+#ifndef SVR_LM_DEEP_COLD
+#define SVR_LM_DEEP_COLD 1           // the slot-per-path pool of deeper paths: lights in LDS, set-up / shading / settling constants through the laundered kernarg pointer
+#endif
 #ifndef SVR_LM_LDS_LIGHTS
 #define SVR_LM_LDS_LIGHTS 1          // the depth-1 pool reads the lights from a copy in LDS (light sampling and settling index them per lane)
 #endif
@@ -761,8 +764,10 @@ enum : uint32_t { LMK_PRIMARY = 0u, LMK_CONT = 1u, LMK_SHADOW = 2u };
 
 template <int LAYOUT, bool COUNT, typename LDS>
 SVR_DEV void lm_walk_pool_deep(const DevScene& s, const LDS& L_, uint32_t* F, const uint32_t* list, uint32_t n, const uint32_t kind, const bool last_bounce,
-                               uint32_t* out, uint32_t& n_out, float* pendL, Cnt& c)
+                               uint32_t* out, uint32_t& n_out, float* pendL, Cnt& c, const DevScene* scp = nullptr, const DevLight* lts = nullptr)
 {
+    const DevScene& sc = scp ? *scp : s;                               // (lights / environment of the settling, as in lm_walk_pool)
+    const DevLight* const LT = SVR_LM_DEEP_COLD ? lts : sc.lights;
     enum : uint32_t { IDLE = 0u, WALK = 1u, TENT = 2u, END = 3u };
     const LmGrid g = lm_grid(s);
     const uint32_t steps_per_turn = s.lm_tune & 0xffu, refill_min = (s.lm_tune >> 8) & 0xffu, ended_min = (s.lm_tune >> 16) & 0xffu;
@@ -835,8 +840,8 @@ SVR_DEV void lm_walk_pool_deep(const DevScene& s, const LDS& L_, uint32_t* F, co
                         // estimate_direct_light's tail (pathtracer.cu:191-198) and L = L + T * Ld (:257)
                         const float ts = hit ? wk.t : -SVR_FLT_MAX;
                         const float Tr = ((ts > tMin) && (ts < wk.tMax)) ? 0.f : 1.f;
-                        const float kf = Tr * (float)s.num_lights;
-                        const DevLight& l = s.lights[(f[SF_META * LM_CAP] >> 4) & 15u];
+                        const float kf = Tr * (float)sc.num_lights;
+                        const DevLight& l = LT[(f[SF_META * LM_CAP] >> 4) & 15u];
                         const v3 B = rec_v3_load(f + SF_B * LM_CAP, LM_CAP), T = rec_v3_load(f + SF_T * LM_CAP, LM_CAP);
                         const float pdf = u2f(f[SF_PDF * LM_CAP]);
                         const v3 L = rec_v3_load(f + SF_L * LM_CAP, LM_CAP) + T * (((B * kf) * V3(l.radiance[0], l.radiance[1], l.radiance[2])) / pdf);
@@ -851,12 +856,12 @@ SVR_DEV void lm_walk_pool_deep(const DevScene& s, const LDS& L_, uint32_t* F, co
                         const uint32_t ls = kind == LMK_PRIMARY ? (f[SF_META * LM_CAP] & 15u) : 0u;
                         const float tt = hit ? wk.t : SVR_FLT_MAX;
                         if (ls != 0u && u2f(f[SF_LST * LM_CAP]) < tt) {
-                            const DevLight& l = s.lights[ls - 1u];
+                            const DevLight& l = LT[ls - 1u];
                             const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -d);
                             put(V3(l.radiance[0], l.radiance[1], l.radiance[2]) * (cosTerm <= 0.f ? 0.f : 1.f));      // (L = 0, T = 1 at k = 0)
                         } else if (!hit) {
                             v3 L = rec_v3_load(f + SF_L * LM_CAP, LM_CAP);
-                            if (s.env_on_escape) L = L + rec_v3_load(f + SF_T * LM_CAP, LM_CAP) * env_radiance(s, d);
+                            if (sc.env_on_escape) L = L + rec_v3_load(f + SF_T * LM_CAP, LM_CAP) * env_radiance(sc, d);
                             put(L);
                         } else {
                             rec_v3_store(f + SF_O * LM_CAP, LM_CAP, o + d * wk.t); rec_v3_store(f + SF_WO * LM_CAP, LM_CAP, -d);
@@ -878,18 +883,20 @@ SVR_DEV void lm_walk_pool_deep(const DevScene& s, const LDS& L_, uint32_t* F, co
 // test (shared by the pixel's frames when the wave is full).  run = the ray has something occupied ahead; otherwise L is final.
 struct LmGen { bool run; v3 L, orig, dir; Rng rng; float ls_t, t0, tMax; int ls_id; };
 template <bool COUNT, typename LDS>
-SVR_DEV LmGen lm_gen(const DevScene& s, const LDS& lds, GroupMapShared* gm, bool live, bool group_march, uint32_t P2, uint32_t x, uint32_t y, uint32_t hashed, Cnt& c)
+SVR_DEV LmGen lm_gen(const DevScene& s, const LDS& lds, GroupMapShared* gm, bool live, bool group_march, uint32_t P2, uint32_t x, uint32_t y, uint32_t hashed, Cnt& c,
+                     const DevScene* scp = nullptr)
 {
+    const DevScene& sc = scp ? *scp : s;
     const float INF = u2f(SVR_INF_BITS);
     LmGen g;
     g.run = false; g.L = V3(0.f, 0.f, 0.f); g.orig = g.L; g.dir = V3(0.f, 0.f, 1.f);
     g.rng = Rng{0u, 0u, 0u, 0u, 0u, 0u};
     g.ls_t = 0.f; g.t0 = 0.f; g.tMax = 0.f; g.ls_id = -1;
     if (live) {
-        rng_init(g.rng, hashed + (y * s.imageW + x));
+        rng_init(g.rng, hashed + (y * sc.imageW + x));
         if (COUNT) c.paths++;
-        camera_ray(s, x, y, g.rng, g.orig, g.dir);
-        g.ls_id = nearest_light(s, g.orig, g.dir, g.ls_t);
+        camera_ray(sc, x, y, g.rng, g.orig, g.dir);
+        g.ls_id = nearest_light(sc, g.orig, g.dir, g.ls_t);
         float tMin = (float)1e-6;
         g.tMax = SVR_FLT_MAX;
         if (group_march) {
@@ -910,10 +917,10 @@ SVR_DEV LmGen lm_gen(const DevScene& s, const LDS& lds, GroupMapShared* gm, bool
         }
         if (!g.run) {
             if (g.ls_id >= 0) {                                           // t = FLT_MAX > ls.t: the light is seen (pathtracer.cu:220-229)
-                const DevLight& l = s.lights[g.ls_id];
+                const DevLight& l = sc.lights[g.ls_id];
                 const float cosTerm = dot(V3(l.normal[0], l.normal[1], l.normal[2]), -g.dir);
                 g.L = V3(l.radiance[0], l.radiance[1], l.radiance[2]) * (cosTerm <= 0.f ? 0.f : 1.f);
-            } else if (s.env_on_escape) g.L = env_radiance(s, g.dir);
+            } else if (sc.env_on_escape) g.L = env_radiance(sc, g.dir);
         }
     }
     return g;
@@ -925,6 +932,18 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
     __shared__ LdsTileCull lds;
     __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
     __shared__ uint32_t pend_task[TILE_WAVES][QUEUE_TASKS];
+    __shared__ DevLight lds_lights[8];                                   // (as in k_trace_lm_pool)
+    if (threadIdx.x < 8u * (sizeof(DevLight) / 4u)) reinterpret_cast<float*>(lds_lights)[threadIdx.x] = reinterpret_cast<const float*>(s.lights)[threadIdx.x];
+    const DevLight* const lts = lds_lights;
+    auto cold_scene = [&]() -> const DevScene* {
+#if SVR_LM_DEEP_COLD
+        auto p = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return (const DevScene*)p;
+#else
+        return nullptr;
+#endif
+    };
     lds_tile_load(lds, s, true);
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -967,7 +986,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             const uint32_t r = (ty << th2) + (pl >> tw2);
             const bool live = px < wv && r < w.n_rows && fslot < w.nframes;
             const bool group_march = fl2 >= 3u && __ballot(live) == ~0ull;
-            const LmGen g = lm_gen<COUNT>(s, lds, &gmaps[wave][0], live, group_march, P2, w.x0 + px, live ? owned_row_to_y(w, r) : 0u, wang_hash(w.frame0 + fslot), c);
+            const LmGen g = lm_gen<COUNT>(s, lds, &gmaps[wave][0], live, group_march, P2, w.x0 + px, live ? owned_row_to_y(w, r) : 0u, wang_hash(w.frame0 + fslot), c, cold_scene());
             {
                 float* p = gpend + (size_t)nb * (3u * 64u) + lane;       // (queued paths overwrite theirs when they end)
                 p[0] = g.L.x; p[64] = g.L.y; p[128] = g.L.z;
@@ -993,7 +1012,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             // ---- walk: this bounce's rays -> hits ----
             uint32_t nH = 0u;
             fence();
-            lm_walk_pool_deep<LAYOUT, COUNT>(s, lds, F, LW, nW, k == 0u ? LMK_PRIMARY : LMK_CONT, last, LH, nH, gpend, c);
+            lm_walk_pool_deep<LAYOUT, COUNT>(s, lds, F, LW, nW, k == 0u ? LMK_PRIMARY : LMK_CONT, last, LH, nH, gpend, c, cold_scene(), lts);
             fence();
             // ---- shade the hits, 64 at a time (VolumeSample + light sampling, pathtracer.cu:237-257) ----
             uint32_t nS = 0u, nA = 0u;
@@ -1010,7 +1029,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
                     Rng rng;
                     rec_rng_load(f + SF_RNG * LM_CAP, LM_CAP, rng);
                     Nee ne;
-                    shade_event<LAYOUT, COUNT>(s, vs, val, rng, ne, c);
+                    shade_event<LAYOUT, COUNT, SVR_LM_DEEP_COLD != 0>(s, vs, val, rng, ne, c, cold_scene(), lts);
                     rec_rng_store(f + SF_RNG * LM_CAP, LM_CAP, rng);
                     if (!last) {                                            // what sample_bsdf needs of the event
                         rec_v3_store(f + SF_GRAD * LM_CAP, LM_CAP, vs.gradient);
@@ -1036,7 +1055,7 @@ __global__ __launch_bounds__(LM_THREADS, SVR_LM_WAVES_PER_EU) void k_trace_lm_po
             }
             // ---- walk: the shadow rays -> A (or final, at the last bounce) ----
             fence();
-            lm_walk_pool_deep<LAYOUT, COUNT>(s, lds, F, LS, nS, LMK_SHADOW, last, LA, nA, gpend, c);
+            lm_walk_pool_deep<LAYOUT, COUNT>(s, lds, F, LS, nS, LMK_SHADOW, last, LA, nA, gpend, c, cold_scene(), lts);
             fence();
             nW = 0u;
             if (last) break;
