@@ -283,12 +283,12 @@ int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_loc
 #define SVR_OPT_MACRO_SHIFT_MIN 32  /* volume textures created from now on get macro-cells of at least 2^v voxels per axis (0..6; default 0 = the smallest cells
                                      * whose grid fits 64^3).  Coarser acceleration data; the default mode's results are unchanged (bit-exact), the local-majorant
                                      * mode's estimate changes with its grid.  For tests of the coarse-grid code paths on small volumes */
-#define SVR_OPT_SPLIT 33            /* many-frame launches of deeper paths (traceDepth >= 2) as TWO kernels (csrc/svr_trace_split.hip): the front half (primary walks, first scatter
-                                     * events and their shadow walks in place) writes the paths that go on into a launch-wide pool of record chunks, the lane machine drains them in a
-                                     * kernel with a register budget of its own (no spilled vector register in its walk loops; the fused kernel spills 60); the frames of the
-                                     * launch go through scratch slots and the resolve kernel.  1 (default; 2 is the same) on, 0 the fused queue kernel.  + 3 % at depth 2, + 5-6 % at
-                                     * depth 3-6.  Needs room for the worst-case pool (14 GB for 64 frames at 1024^2; the fused kernel renders if the device has none, for media
-                                     * whose primary walks are pooled, and for launches of < 8 frames).  Results unchanged (bit-exact) */
+#define SVR_OPT_SPLIT 33            /* OPT-IN, default 0: many-frame launches of deeper paths (traceDepth >= 2) as TWO kernels (csrc/svr_trace_split.hip): the front half (primary walks,
+                                     * first scatter events and their shadow walks in place) writes the paths that go on into a launch-wide pool of record chunks, the lane machine
+                                     * drains them in a kernel with a register budget of its own; the frames of the launch go through scratch slots and the resolve kernel.  Built to
+                                     * give the machine its own registers (+ 3-6 % over the fused kernel of the time); the fused kernel has since caught up and is 0.5-1.5 % ahead
+                                     * without the pool, so this is off by default.  1 / 2: on.  Needs room for the worst-case pool (14 GB for 64 frames at 1024^2; else the fused
+                                     * kernel renders; also for media whose primary walks are pooled and for launches of < 8 frames).  Results unchanged (bit-exact) */
 #define SVR_OPT_ENV_NEE 34          /* OPT-IN, default 0: importance sampling of the environment MAP (csrc/svr_trace_env.hip).  With SVR_OPT_ENV_ON_ESCAPE the environment lights the
                                      * medium only through the directions the BSDF / phase sampling picks (core/lights/cuda_environment_light.h:58-72 is a lookup, nothing more).
                                      * 1: every scatter event that is followed by a bounce also draws one direction from the map's luminance (a table built on the GPU by

@@ -129,7 +129,7 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1, opt_nan_guard = 0, opt_macro_shift_min = 0, opt_split = 1, opt_env_nee = 0;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1, opt_nan_guard = 0, opt_macro_shift_min = 0, opt_split = 0, opt_env_nee = 0;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
@@ -713,7 +713,10 @@ int render_frames(void* img, const svr_render_params* rp, uint32_t nframes, bool
     // index, and the device has room for the worst-case record pool of a launch (<= 24 GB; else the fused kernel)
     bool use_split = false;
     const uint32_t split_group = (uint32_t)g.opt_group_frames;
-    // (same-box A/B, c3, two kernels / fused: depth 2 5 025 / 4 880, depth 3 3 745 / 3 555, depth 4 3 164 / 2 990, depth 6 2 800+ / 2 690: from depth 2 on)
+    // OPT-IN since the fused kernel caught up: the two changes that made the split machine fast (lights in LDS + laundered scene constants) also fix the fused
+    // deeper kernel when applied TOGETHER (each alone costs it 2.5-8 %).  Same box, two kernels / fused: depth 2 5 048 / 5 120, depth 3 3 735 / 3 782,
+    // depth 4 3 152 / 3 171, depth 6 2 844 / 2 876, c5 depth 2 3 306 / 3 333, c3b depth 4 1 846 / 1 830 -- and the fused form needs no 14-GB pool.
+    // (Against the fused kernel as it was, the two-kernel form won 3-6 %: 5 054 / 4 893, 3 728 / 3 555, 3 161 / 2 988, 2 859 / 2 693.)
     if (g.opt_split && use_queue && rp->traceDepth >= 2u && rp->traceDepth < 32768u && !cfg.pool_primary && !local_majorant && !g.opt_fast_math && nframes >= 8 &&
         s.layout != svr::LAYOUT_LINEAR && (uint64_t)s.imageW * s.imageH <= (1ull << 26) && !frame_ahead_possible) {
         svr::DevWork wq;

@@ -194,13 +194,20 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
 #ifndef SVR_LDS_LIGHTS
 #define SVR_LDS_LIGHTS 1
 #endif
-    __shared__ DevLight lds_lights[QUEUE && DEPTH1 && SVR_LDS_LIGHTS ? 8 : 1];
-    if constexpr (QUEUE && DEPTH1 && SVR_LDS_LIGHTS) {
+#ifndef SVR_COLD_DEEP_POOL
+#define SVR_COLD_DEEP_POOL 1           // the deeper build with pooled primary walks (fog: c3n at depth >= 2) gains 12.5 % with both (1 255 -> 1 412, 835 -> 940)
+#endif
+#ifndef SVR_COLD_DEEP_ALL
+#define SVR_COLD_DEEP_ALL 1            // ... and so does the fused deeper build without pooled walks -- with BOTH: 4 897 -> 5 115 at depth 2, 2 995 -> 3 176 at depth 4 (same box),
+                                       // while the laundered constants alone cost it 8 % and the LDS lights alone 2.5 %
+#endif
+    __shared__ DevLight lds_lights[QUEUE && SVR_LDS_LIGHTS ? 8 : 1];
+    if constexpr (QUEUE && SVR_LDS_LIGHTS) {
         if (threadIdx.x < 8u * (sizeof(DevLight) / 4u))
             reinterpret_cast<float*>(lds_lights)[threadIdx.x] = reinterpret_cast<const float*>(s.lights)[threadIdx.x];
     }
     // (traceDepth-1 builds: same-box A/B c3 9 626-9 805 against 9 522-9 526, c3n 2 403 / 2 386, c5 6 549 / 6 489; the deeper build loses 2.5 % with it)
-    constexpr bool LDSL = QUEUE && DEPTH1 && SVR_LDS_LIGHTS;
+    constexpr bool LDSL = QUEUE && (DEPTH1 || (POOL && SVR_COLD_DEEP_POOL) || SVR_COLD_DEEP_ALL) && SVR_LDS_LIGHTS;
     const DevLight* const lts = lds_lights;
     lds_tile_load(lds, s, SKIP);
 
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
     auto cold_scene = [&]() -> const DevScene* {
         // (traceDepth-1 builds only: same-box A/B c3 9 690 against 9 500, c3n 2 381 / 2 351, c5 6 561 / 6 438; the deeper build LOSES 8 % with it --
         // 4 508 against 4 884 at depth 2 -- its services settle walks one scalar load latency at a time)
-        if constexpr (QUEUE && DEPTH1 && SVR_COLD_SCENE) {
+        if constexpr (QUEUE && (DEPTH1 || (POOL && SVR_COLD_DEEP_POOL) || SVR_COLD_DEEP_ALL) && SVR_COLD_SCENE) {
             auto p = __builtin_amdgcn_kernarg_segment_ptr();          // (a pointer into the constant address space: the loads stay scalar)
             asm volatile("" : "+s"(p));
             return (const DevScene*)p;

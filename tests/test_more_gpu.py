@@ -785,7 +785,7 @@ def test_split_kernels_bit_exact(hip_dev, name, depth):
             try:
                 hdr, img, c = hip_frames(hip_dev, sc, frames, batch=True)
             finally:
-                hip_dev.set_option(abi.OPT_SPLIT, 1)
+                hip_dev.set_option(abi.OPT_SPLIT, 0)
             assert_bit_exact(hdr, ref_hdr, f"{name} depth {depth}, {frames} frames, SVR_OPT_SPLIT = {split}")
             assert np.array_equal(img, ref_img)
             assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"]
@@ -806,7 +806,7 @@ def test_split_and_direct_builds_under_a_window_and_a_row_shard(hip_dev, case):
         # batch = one 72-frame call (a 64-frame and an 8-frame launch); per-frame calls = frames traced ahead (batches up to 64, DIRECT builds)
         hdr, _, _ = hip_frames(hip_dev, sc, frames, batch="direct" not in case, count=False, **kw)
     finally:
-        hip_dev.set_option(abi.OPT_SPLIT, 1)
+        hip_dev.set_option(abi.OPT_SPLIT, 0)
     if "window" in case:
         x0, y0, x1, y1 = kw["window"]
         assert_bit_exact(hdr[y0:y1, x0:x1], ref_hdr[y0:y1, x0:x1], case)
