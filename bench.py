@@ -535,8 +535,6 @@ def main():
             r2 = roofline_block(c2, S, n, ms2, n2, rec)
             if lm:
                 r2["kernel"] = "k_trace_lm"
-            elif depth >= 3 and sc_name != "c3n":
-                r2["kernel"] = "k_split_front + k_split_machine"       # (deeper paths as two kernels: `kernel_avg_ms` is the pair)
             extra[tag] = {"value": round(float(W) * H * S * n / dt / 1e6, 3), "unit": "Msamples/s", "steps": n,
                           "ms_per_step": round(dt / n * 1e3, 3), "trace_depth": depth, "what": what, "roofline": r2}
             dev.set_option(abi.OPT_EMPTY_SKIP, args.empty_skip)

@@ -10,8 +10,8 @@ SPECS=${SPECS:-"c3_d1:--scene c3|c3_d1_noskip:--scene c3 --empty-skip 0|c3n_d1:-
 IFS='|' read -ra SPEC_LIST <<< "$SPECS"
 for spec in "${SPEC_LIST[@]}"; do
   tag=${spec%%:*}; args=${spec#*:}
-  # (deeper paths from traceDepth 3 on run as two kernels, svr_trace_split.hip -- except media whose primary walks are pooled: c3n)
-  kern=k_trace_tile; case $tag in *_lm) kern=k_trace_lm;; c3_d4|c3_d6|c5_d4) kern=k_split_front+k_split_machine;; esac
+  # (the opt-in two-kernel form of deeper paths, --set split=1, would be kern=k_split_front+k_split_machine)
+  kern=k_trace_tile; case $tag in *_lm) kern=k_trace_lm;; *_split) kern=k_split_front+k_split_machine;; esac
   echo "=== $tag ($args)"
   PROF_STEPS=${PROF_STEPS:-1} bash tools/profile.sh ${R}_$tag $args --spp-per-step ${PROF_SPP:-64} > gpurun_out/prof_${R}_$tag.log 2>&1 || { echo "profile $tag failed"; tail -5 gpurun_out/prof_${R}_$tag.log; exit 1; }
   python3 tools/pmc_json.py gpurun_out/prof_${R}_$tag/summary.txt "$kern" $tag gpurun_out/prof_${R}_$tag/pmc.json "bench.py $args --spp-per-step ${PROF_SPP:-64} (64 frames per launch)" | cut -c1-400
