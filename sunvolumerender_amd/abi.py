@@ -155,6 +155,7 @@ OPT_NAN_GUARD = 31
 OPT_MACRO_SHIFT_MIN = 32
 OPT_SPLIT = 33
 OPT_ENV_NEE = 34
+OPT_FAST_BOUND = 35
 KERNEL_AUTO, KERNEL_PIXEL, KERNEL_TILE, KERNEL_ULOOP, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4
 
 ELEM_I8, ELEM_U8, ELEM_I16, ELEM_U16, ELEM_I32, ELEM_U32, ELEM_F32, ELEM_F64 = range(8)

@@ -16,17 +16,18 @@
 
 namespace svr {
 
+// pad > 0 (the WIDE table of the fast bound look-up, k_bound8): the footprint grows by `pad` voxels on every side.
 __global__ __launch_bounds__(64) void k_minmax(const uint16_t* __restrict__ src, uint16_t* __restrict__ mm,
-                                               int nx, int ny, int nz, int shift, int gx, int gy, int gz)
+                                               int nx, int ny, int nz, int shift, int gx, int gy, int gz, int pad)
 {
     const int S = 1 << shift;
     uint32_t m = blockIdx.x;
     int mx = (int)(m % (uint32_t)gx);
     int my = (int)((m / (uint32_t)gx) % (uint32_t)gy);
     int mz = (int)(m / ((uint32_t)gx * (uint32_t)gy));
-    int x0 = mx * S - 1, y0 = my * S - 1, z0 = mz * S - 1;
+    int x0 = mx * S - 1 - pad, y0 = my * S - 1 - pad, z0 = mz * S - 1 - pad;
     // voxels per axis in the footprint (+1 on the last macro-cell: border voxel N)
-    int Ex = S + 1 + (mx == gx - 1), Ey = S + 1 + (my == gy - 1), Ez = S + 1 + (mz == gz - 1);
+    int Ex = S + 1 + 2 * pad + (mx == gx - 1), Ey = S + 1 + 2 * pad + (my == gy - 1), Ez = S + 1 + 2 * pad + (mz == gz - 1);
     int total = Ex * Ey * Ez;
     uint32_t lo = 0xffffu, hi = 0u;
     for (int e = threadIdx.x; e < total; e += 64) {
@@ -96,6 +97,32 @@ __device__ inline float bound_thr(uint32_t c)
     return (k & 1u) ? p * 1.41421356237f : p;
 }
 
+// b = the largest value of  sigma_t * invSigmaMax  any fetch can produce whose raw footprint lies in [rlo, rhi]; bad: not a number
+// somewhere (no bound)
+__device__ inline float accept_bound(float rlo, float rhi, const float* __restrict__ tf, int tf_n, float densityScale, float invSigmaMax, bool& bad)
+{
+    const float nf = (float)tf_n;
+    float ilo = (rlo * 1.5259021896696422e-05f) * densityScale;      // the two multiplies of tex_fetch / intensity_at
+    float ihi = (rhi * 1.5259021896696422e-05f) * densityScale;
+    if (!(ilo == ilo) || !(ihi == ihi)) { bad = true; return 0.f; }
+    if (ihi < ilo) { float t = ilo; ilo = ihi; ihi = t; }
+    const float xl = fmin_(fmax_(fma_(ilo, nf, -0.5f), -1.f), nf);   // lds_tf_coord
+    const float xh = fmin_(fmax_(fma_(ihi, nf, -0.5f), -1.f), nf);
+    const int e_lo = (int)__builtin_floorf(xl) + 1;
+    const int e_hi = (int)__builtin_floorf(xh) + 2;
+    float amax = 0.f;
+    bad = false;
+    for (int e = e_lo; e <= e_hi; ++e) {                              // padded table: entry e = alpha of texel clamp(e - 1)
+        const int t = min(max(e - 1, 0), tf_n - 1);
+        const float a = tf[4 * t + 3];
+        bad = bad || !(a == a);
+        amax = fmax_(amax, a);
+    }
+    const float b = amax * invSigmaMax;                               // the product of the accept test
+    bad = bad || !(b == b);
+    return b;
+}
+
 __global__ __launch_bounds__(256) void k_bound_class(const uint16_t* __restrict__ mm, int gx, int gy, int gz, int hgx, int hgy, int hgz,
                                                      const float* __restrict__ tf, int tf_n, float densityScale, float invSigmaMax,
                                                      uint32_t* __restrict__ cls, float* __restrict__ thr, uint32_t* __restrict__ census)
@@ -105,32 +132,15 @@ __global__ __launch_bounds__(256) void k_bound_class(const uint16_t* __restrict_
     const uint32_t hn = (uint32_t)hgx * (uint32_t)hgy * (uint32_t)hgz;
     if (hq >= hn) return;
     const int hx = (int)(hq % (uint32_t)hgx), hy = (int)((hq / (uint32_t)hgx) % (uint32_t)hgy), hz = (int)(hq / ((uint32_t)hgx * (uint32_t)hgy));
-    const float nf = (float)tf_n;
     uint32_t c_max = 0u;
     for (int d = 0; d < 8; ++d) {
         const int x = 2 * hx + (d & 1), y = 2 * hy + ((d >> 1) & 1), z = 2 * hz + (d >> 2);
         if (x >= gx || y >= gy || z >= gz) continue;
         const size_t m = (size_t)x + (size_t)gx * ((size_t)y + (size_t)gy * (size_t)z);
-        const float rlo = (float)mm[2 * m], rhi = (float)mm[2 * m + 1];
-        float ilo = (rlo * 1.5259021896696422e-05f) * densityScale;      // the two multiplies of tex_fetch / intensity_at
-        float ihi = (rhi * 1.5259021896696422e-05f) * densityScale;
-        if (!(ilo == ilo) || !(ihi == ihi)) { c_max = BOUND_CLASSES - 1u; break; }
-        if (ihi < ilo) { float t = ilo; ilo = ihi; ihi = t; }
-        const float xl = fmin_(fmax_(fma_(ilo, nf, -0.5f), -1.f), nf);   // lds_tf_coord
-        const float xh = fmin_(fmax_(fma_(ihi, nf, -0.5f), -1.f), nf);
-        const int e_lo = (int)__builtin_floorf(xl) + 1;
-        const int e_hi = (int)__builtin_floorf(xh) + 2;
-        float amax = 0.f;
-        bool bad = false;
-        for (int e = e_lo; e <= e_hi; ++e) {                              // padded table: entry e = alpha of texel clamp(e - 1)
-            const int t = min(max(e - 1, 0), tf_n - 1);
-            const float a = tf[4 * t + 3];
-            bad = bad || !(a == a);
-            amax = fmax_(amax, a);
-        }
-        const float b = amax * invSigmaMax;                               // the product of the accept test
+        bool bad;
+        const float b = accept_bound((float)mm[2 * m], (float)mm[2 * m + 1], tf, tf_n, densityScale, invSigmaMax, bad);
         uint32_t c = BOUND_CLASSES - 1u;
-        if (!bad && b == b)
+        if (!bad)
             for (uint32_t k = 0; k < BOUND_CLASSES; ++k)
                 if (b <= bound_thr(k)) { c = k; break; }
         c_max = max(c_max, c);
@@ -142,6 +152,49 @@ __global__ __launch_bounds__(256) void k_bound_class(const uint16_t* __restrict_
         if (partial) atomicAdd(&census[0], (uint32_t)__popcll(partial));
         if (full) atomicAdd(&census[1], (uint32_t)__popcll(full));
     }
+}
+
+// FAST BOUND LOOK-UP (bit-exact; svr_lanes.hpp, iterate_rot).  Any valid upper bound of sigma_t * invSigmaMax culls correctly -- a culled draw is
+// a rejection whatever the voxels hold -- so the look-up need not find the exact trilinear cell of the tap: the lane machine takes the
+// half-resolution macro-cell from ONE fma per axis on the ray parameter (13 vector instructions where cell_of + cell_info take ~50), which may
+// differ from the reference's float chain by a rounding error (far below one voxel: the host checks the camera distance that guarantees it), and this
+// table bounds every fetch within one more voxel around each cell (mm_wide: launch_minmax with pad 1).  Walks stay inside the clipped box, the
+// box inside the texture domain (the host checks that too), so the coordinate lies within [-eps, grid + 1/2 voxel + eps]: the table carries one
+// more cell around the grid and the look-up adds 1 instead of clamping.  It also drops the second look-up
+// (class -> threshold) and the conversion of the draw: the byte B is compared with the top 8 bits of the draw's RANDOM WORD x,
+//     cull  <=>  (x >> 24) > B,     B = min(255, X(b) >> 24),  X(b) = the smallest word with rng_to_uniform(X) >= b  (2^32 if none)
+// -- rng_to_uniform is monotone, so (x >> 24) > B implies x >= X(b), i.e. xi >= b.  Linear in the bound with 1/256 resolution (the classes'
+// steps of sqrt 2 waste up to 41 % of a cell's fetches; this wastes 0.4 % of the iterations), B = 255: every draw fetches.
+__global__ __launch_bounds__(256) void k_bound8(const uint16_t* __restrict__ mmw, int hgx, int hgy, int hgz, const float* __restrict__ tf, int tf_n, float densityScale,
+                                                float invSigmaMax, uint8_t* __restrict__ bnd8)
+{
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= BOUND8_BYTES) return;
+    const uint32_t px = (uint32_t)hgx + 2u, py = (uint32_t)hgy + 2u, pz = (uint32_t)hgz + 2u;
+    if (e >= px * py * pz) { bnd8[e] = 255u; return; }
+    // entry (x + 1, y + 1, z + 1) = cell (x, y, z); the entries around the grid repeat its edge cells
+    const int x = min(max((int)(e % px) - 1, 0), hgx - 1), y = min(max((int)((e / px) % py) - 1, 0), hgy - 1), z = min(max((int)(e / (px * py)) - 1, 0), hgz - 1);
+    const uint32_t hq = (uint32_t)x + (uint32_t)hgx * ((uint32_t)y + (uint32_t)hgy * (uint32_t)z);
+    bool bad;
+    const float b = accept_bound((float)mmw[2 * (size_t)hq], (float)mmw[2 * (size_t)hq + 1], tf, tf_n, densityScale, invSigmaMax, bad);
+    uint32_t B = 255u;
+    if (!bad) {
+        uint64_t lo = 0ull, hi = 1ull << 32;                        // X(b) by bisection on the monotone conversion
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (rng_to_uniform((uint32_t)mid) >= b) hi = mid; else lo = mid + 1ull;
+        }
+        B = min(255u, (uint32_t)(lo >> 24));
+    }
+    bnd8[e] = (uint8_t)B;
+}
+
+hipError_t launch_bound8(const uint16_t* mm_wide, int hgx, int hgy, int hgz, const float* tf_rgba, int tf_n, float densityScale,
+                         float invSigmaMax, uint8_t* bnd8, hipStream_t st)
+{
+    if ((uint64_t)(hgx + 2) * (uint64_t)(hgy + 2) * (uint64_t)(hgz + 2) > BOUND8_BYTES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bound8, dim3(BOUND8_BYTES / 256u), dim3(256), 0, st, mm_wide, hgx, hgy, hgz, tf_rgba, tf_n, densityScale, invSigmaMax, bnd8);
+    return hipGetLastError();
 }
 
 hipError_t launch_fine_mask(const uint16_t* mm, uint32_t n_cells, const uint32_t* tf_zero_prefix, int tf_n, float densityScale,
@@ -191,10 +244,10 @@ hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const 
 }
 
 hipError_t launch_minmax(const uint16_t* src, uint16_t* mm, int nx, int ny, int nz, int shift,
-                         int gx, int gy, int gz, hipStream_t st)
+                         int gx, int gy, int gz, hipStream_t st, int pad)
 {
     uint32_t n = (uint32_t)gx * (uint32_t)gy * (uint32_t)gz;
-    hipLaunchKernelGGL(k_minmax, dim3(n), dim3(64), 0, st, src, mm, nx, ny, nz, shift, gx, gy, gz);
+    hipLaunchKernelGGL(k_minmax, dim3(n), dim3(64), 0, st, src, mm, nx, ny, nz, shift, gx, gy, gz, pad);
     return hipGetLastError();
 }
 

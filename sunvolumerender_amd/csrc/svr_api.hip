@@ -55,6 +55,7 @@ struct Texture {
     // a second, finer level (macro-cells of half the edge) when the LDS-resident grid is coarse (mc_shift >= 1): its `empty`
     // bits live in global memory and are consulted for fetches in cells the coarse level cannot rule out
     uint16_t* mm_fine = nullptr;
+    uint16_t* mm_wide = nullptr;       // min/max per HALF-resolution macro-cell over a footprint one voxel wider per side (the fast bound look-up, svr_accel.hip k_bound8)
     int fg_x = 0, fg_y = 0, fg_z = 0;
     // environment map: sampling table of SVR_OPT_ENV_NEE (svr_kernels.hip launch_env_cdf), built with the texture
     float* env_cdf = nullptr;
@@ -129,13 +130,15 @@ struct Context {
     size_t slot_floats = 0;        // floats per scratch slot currently allocated (3*W*H)
     uint32_t slots_per_set = 0;    // slots currently allocated per set
     int next_set = 0;
-    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1, opt_nan_guard = 0, opt_macro_shift_min = 0, opt_split = 0, opt_env_nee = 0;
+    int opt_pipeline = 1, opt_refill = 16, opt_empty_skip = 1, opt_ray_skip = 1, opt_debug_stop = 0, opt_frames_log2 = -1, opt_unit = 0, opt_rc_lanes = 3, opt_bound_cull = 1, opt_park_end = 32, opt_fold = 1, opt_queue = 1, opt_fast_math = 0, opt_fine_mask = 0, opt_row_order = 0, opt_group_frames = 64, opt_local_majorant = 0, opt_light_cull = 1, opt_lm_tune = 0, opt_lm_sub = 1, opt_park_cheap = 16, opt_pinhole_fast = 1, opt_pool = 1, opt_trips = 1, opt_nan_guard = 0, opt_macro_shift_min = 0, opt_split = 0, opt_env_nee = 0, opt_fast_bound = 1;
     // empty-space bitmask of the current (volume, transfer function, densityScale)
     uint32_t* d_mask = nullptr;
     uint32_t* d_fine_mask = nullptr;   // `empty` bits of the fine level (global memory), sized for the current volume
     size_t fine_mask_words = 0;
+    uint8_t* d_bnd8 = nullptr;         // byte table of the fast bound look-up (svr::BOUND8_BYTES)
     uint8_t* d_sub8 = nullptr;         // occupancy of the fine cells inside every macro-cell (local-majorant walks), MASK_WORDS_MAX * 32 bytes
     bool sub8_valid = false;
+    bool bnd8_valid = false;
     uint8_t* d_mask_tmp = nullptr;     // scratch of the distance transform
     bool mask_valid = false;
     uint64_t mask_vol = 0, mask_tf = 0, mask_tf_version = 0;
@@ -497,6 +500,13 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
         g.sub8_valid = tv->mm_fine != nullptr;
         HIP_TRY(svr::launch_bound_class(tv->mm, tv->mc_gx, tv->mc_gy, tv->mc_gz, (const float*)tt->data, tt->nx, vol.densityScale,
                                         s.invSigmaMax, g.d_mask, g.stream));
+        g.bnd8_valid = false;
+        if (tv->mm_wide) {
+            if (!g.d_bnd8) HIP_TRY(hipMalloc((void**)&g.d_bnd8, svr::BOUND8_BYTES));
+            HIP_TRY(svr::launch_bound8(tv->mm_wide, (tv->mc_gx + 1) / 2, (tv->mc_gy + 1) / 2, (tv->mc_gz + 1) / 2, (const float*)tt->data, tt->nx, vol.densityScale,
+                                       s.invSigmaMax, g.d_bnd8, g.stream));
+            g.bnd8_valid = true;
+        }
         HIP_TRY(hipStreamSynchronize(g.stream));
         // the bound test costs two dependent LDS reads per tested cell (4 % on a scene where it never rejects anything): use
         // it where at least 2 % of the coarse cells that can hold a collision have a bound below 1
@@ -553,6 +563,26 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
     // five-iteration trips of the lane machine: walks of tens of iterations with few fetches -- media without exactly transparent space under
     // bound culling (c3n: +20 %; c3 / c5 at depth 2: -1..2 %)
     s.trips = (g.opt_trips == 2 || (g.opt_trips == 1 && s.bound_cull && !s.has_empty)) ? 1u : 0u;
+    // Fast bound look-up of the lane machine's trips (svr_lanes.hpp iterate_rot; svr_accel.hip k_bound8): media without exactly transparent space under
+    // bound culling.  The look-up takes the macro-cell from one fma per axis on the ray parameter; the table covers one voxel of error, the float chains
+    // differ by ~8 ulp of the largest intermediate -- |origin - volume| * N voxels * 2^-21 -- so the camera may be up to 2^21 / (16 N) volume extents
+    // away (128 at N = 1024; scatter points and shadow rays start inside the volume) before the kernel falls back to the exact cell.  The look-up
+    // does not clamp: the clipped box must lie inside the texture domain (`inside`), as for the whole-ray tests.
+    s.bnd8 = nullptr;
+    s.hc_scale[0] = 0.5f * s.mc_scale[0]; s.hc_scale[1] = 0.5f * s.mc_scale[1]; s.hc_scale[2] = 0.5f * s.mc_scale[2];
+    s.hc_off = 0.5f * s.mc_off + 1.f;
+    s.hc_sy = (uint32_t)((tv->mc_gx + 1) / 2 + 2); s.hc_sz = s.hc_sy * (uint32_t)((tv->mc_gy + 1) / 2 + 2);
+    if (g.opt_fast_bound && g.bnd8_valid && s.bound_cull && !s.has_empty && s.fine_mask == nullptr && s.trips && inside) {
+        bool near_enough = true;
+        const int nmax = tv->nx > tv->ny ? (tv->nx > tv->nz ? tv->nx : tv->nz) : (tv->ny > tv->nz ? tv->ny : tv->nz);
+        const double reach = 2097152.0 / (16.0 * (double)nmax);
+        for (int a = 0; a < 3; ++a) {
+            const double c = 0.5 * ((double)lo[a] + (double)hi[a]), ext = (double)hi[a] - (double)lo[a];
+            const double d = ((double)s.cam_pos[a] - c) / ext;
+            near_enough = near_enough && ext > 0.0 && d == d && (d < 0 ? -d : d) <= reach;
+        }
+        if (near_enough) s.bnd8 = g.d_bnd8;
+    }
     return 0;
 }
 
@@ -983,6 +1013,7 @@ void svr_shutdown(void)
         if (kv.second->data) hipFree(kv.second->data);
         if (kv.second->mm) hipFree(kv.second->mm);
         if (kv.second->mm_fine) hipFree(kv.second->mm_fine);
+        if (kv.second->mm_wide) hipFree(kv.second->mm_wide);
         if (kv.second->zero_prefix) hipFree(kv.second->zero_prefix);
         if (kv.second->env_cdf) hipFree(kv.second->env_cdf);
         delete kv.second;
@@ -1000,6 +1031,7 @@ void svr_shutdown(void)
     if (g.d_mask_tmp) hipFree(g.d_mask_tmp);
     if (g.d_fine_mask) hipFree(g.d_fine_mask);
     if (g.d_sub8) hipFree(g.d_sub8);
+    if (g.d_bnd8) hipFree(g.d_bnd8);
     if (g.d_counters) hipFree(g.d_counters);
     if (g.d_ticket) hipFree(g.d_ticket);
     if (g.d_queue) hipFree(g.d_queue);
@@ -1127,6 +1159,12 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
         e = hipMalloc((void**)&t->mm_fine, (size_t)t->fg_x * t->fg_y * t->fg_z * 2 * sizeof(uint16_t));
         if (e == hipSuccess) e = svr::launch_minmax(d_src, t->mm_fine, nx, ny, nz, fs, t->fg_x, t->fg_y, t->fg_z, g.stream);
     }
+    if (e == hipSuccess) {
+        // the wide table of the fast bound look-up: half-resolution macro-cells (cells of 2^(shift + 1)), footprints one voxel wider per side
+        const int hgx = (t->mc_gx + 1) / 2, hgy = (t->mc_gy + 1) / 2, hgz = (t->mc_gz + 1) / 2;
+        e = hipMalloc((void**)&t->mm_wide, (size_t)hgx * hgy * hgz * 2 * sizeof(uint16_t));
+        if (e == hipSuccess) e = svr::launch_minmax(d_src, t->mm_wide, nx, ny, nz, t->mc_shift + 1, hgx, hgy, hgz, g.stream, 1);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
     if (staged) hipFree(staged);
     if (e != hipSuccess) {
@@ -1134,6 +1172,7 @@ static uint64_t create_volume_texture(const uint16_t* voxels, int nx, int ny, in
         if (t->data) hipFree(t->data);
         if (t->mm) hipFree(t->mm);
         if (t->mm_fine) hipFree(t->mm_fine);
+        if (t->mm_wide) hipFree(t->mm_wide);
         delete t;
         if (retry) { (void)hipGetLastError(); *oom = true; return 0; }
         fail((int)e, "volume texture creation failed: %s", hipGetErrorName(e));
@@ -1231,6 +1270,7 @@ int svr_destroy_texture(uint64_t handle)
     if (t->data) hipFree(t->data);
     if (t->mm) hipFree(t->mm);
     if (t->mm_fine) hipFree(t->mm_fine);
+    if (t->mm_wide) hipFree(t->mm_wide);
     if (t->zero_prefix) hipFree(t->zero_prefix);
     if (t->env_cdf) hipFree(t->env_cdf);
     if (g.mask_vol == handle || g.mask_tf == handle) g.mask_valid = false;
@@ -1568,6 +1608,7 @@ int svr_set_option(int key, int value)
         g.opt_split = value; g.split_alloc_failed = false; return 0;
     case SVR_OPT_ENV_NEE: g.opt_env_nee = value ? 1 : 0; g.ahead[0].valid = g.ahead[1].valid = false; return 0;
     case SVR_OPT_NAN_GUARD: g.opt_nan_guard = value ? 1 : 0; return 0;
+    case SVR_OPT_FAST_BOUND: g.opt_fast_bound = value ? 1 : 0; return 0;
     case SVR_OPT_MACRO_SHIFT_MIN:
         if (value < 0 || value > 6) return fail(-6, "SVR_OPT_MACRO_SHIFT_MIN: bad value %d (0..6)", value);
         g.opt_macro_shift_min = value; return 0;
@@ -1620,6 +1661,7 @@ int svr_get_option(int key)
     case SVR_OPT_TRIPS: return g.opt_trips;
     case SVR_OPT_SPLIT: return g.opt_split;
     case SVR_OPT_ENV_NEE: return g.opt_env_nee;
+    case SVR_OPT_FAST_BOUND: return g.opt_fast_bound;
     case SVR_OPT_NAN_GUARD: return g.opt_nan_guard;
     case SVR_OPT_MACRO_SHIFT_MIN: return g.opt_macro_shift_min;
     case SVR_OPT_REFILL_MIN_IDLE: return g.opt_refill;

@@ -29,7 +29,19 @@ SVR_DEV void rng_init(Rng& r, uint32_t seed)
 }
 
 // curand_uniform's mapping of the draw's integer x = v4 + d
-SVR_DEV float rng_to_uniform(uint32_t x) { return (float)x * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
+// _curand_uniform: x * 2^-32 + 2^-33, a multiply and an add.  The product is EXACT (a power-of-two scaling of a float in [0, 2^32], nowhere near the
+// subnormals), so the one rounding of a fused multiply-add is the add's: the same bits in one instruction instead of two.
+#ifndef SVR_UNIFORM_FMA
+#define SVR_UNIFORM_FMA 1
+#endif
+SVR_DEV float rng_to_uniform(uint32_t x)
+{
+#if SVR_UNIFORM_FMA
+    return __builtin_fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+#else
+    return (float)x * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
+#endif
+}
 
 SVR_DEV float rng_uniform(Rng& r)
 {

@@ -72,8 +72,9 @@ hipError_t launch_trace_lm(const DevScene& scene, const DevWork& work, const Lau
 hipError_t launch_wavefront(const DevScene& scene, const DevWork& work, const LaunchCfg& cfg, float4* const* planes,
                             uint32_t* counts, uint32_t capacity, hipStream_t stream);
 // acceleration data (svr_accel.hip): per-macro-cell min/max of the raw voxels, and the empty bitmask
+// pad: the footprint of every cell grown by that many voxels per side (1: the wide table of launch_bound8)
 hipError_t launch_minmax(const uint16_t* src_linear, uint16_t* mm, int nx, int ny, int nz, int shift,
-                         int gx, int gy, int gz, hipStream_t stream);
+                         int gx, int gy, int gz, hipStream_t stream, int pad = 0);
 // mask: [0, DIST_WORDS_MAX) = half-resolution 4-bit distance field (distance to the nearest non-empty macro-cell),
 // then MASK_WORDS_MAX words of deep-empty bits (distance >= 2, full resolution), then mask_words words of `empty`
 // bits; tmp: 2 * gx*gy*gz bytes of scratch
@@ -87,6 +88,13 @@ hipError_t launch_sub8(const uint32_t* fine_empty, int fgx, int fgy, int fgz, in
 // bound classes of the half-resolution macro-cells (4 bit each) + the BOUND_CLASSES thresholds, into accel + ACCEL_CLASS_OFF
 hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const float* tf_rgba, int tf_n, float densityScale,
                               float invSigmaMax, uint32_t* accel, hipStream_t stream);
+// fast bound look-up of the lane machine (svr_lanes.hpp, iterate_rot): one byte per half-resolution macro-cell from the WIDE min/max table
+// (footprints grown by one voxel: launch_minmax with shift + 1, pad 1) -- a fetch is needed only if (accept draw's random word >> 24) <= byte.
+// The table has one more cell on EVERY side of the grid (copies of the edge cells; rows of hgx + 2, slices of (hgx + 2)(hgy + 2)), so the
+// look-up needs no clamp: cell (x, y, z) of the grid is entry (x + 1, y + 1, z + 1).
+constexpr uint32_t BOUND8_BYTES = 40960u;          // >= 34^3: up to 32^3 half-resolution cells
+hipError_t launch_bound8(const uint16_t* mm_wide, int hgx, int hgy, int hgz, const float* tf_rgba, int tf_n, float densityScale,
+                         float invSigmaMax, uint8_t* bnd8, hipStream_t stream);
 // rows of one rank of a row-strip shard: packed (n_rows x row_floats) <-> full frame; to_packed: 1 = pack, 0 = unpack
 hipError_t launch_strips(float* packed, float* frame, uint32_t row_floats, uint32_t n_rows, uint32_t strip_rows, uint32_t rank, uint32_t world,
                          int to_packed, hipStream_t stream);

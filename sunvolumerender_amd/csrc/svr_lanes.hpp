@@ -256,6 +256,7 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
     enum : uint32_t { IDLE = 0u, CELL = 1u, WALK = 2u, FETCH = 3u, MARCH = 4u, END = 5u, WANT_A = 6u, WANT_B = 7u };
     const float INF = u2f(SVR_INF_BITS);
     const uint32_t traceDepth = DEPTH1 ? 1u : traceDepth_;
+    const bool fast_bound = lds_has_bnd8<LDS>::value && s.bnd8 != nullptr;      // (SVR_OPT_FAST_BOUND; media without exactly transparent space)
     uint32_t st = IDLE;
     // walk state
     Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
@@ -319,7 +320,7 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
     // operations of a lane are those of iterate(), in the same order: scheduling only.  A lane that left waits for the end of
     // the trip (13 % of the iterations of c3n ask for a fetch: 3.85 of 5 iteration slots are used), and the fetch service runs
     // once per trip for half of the lanes instead of once per iteration for an eighth.
-    auto iterate_rot = [&](auto hd, auto jj, bool& in, uint32_t& steps, const uint32_t d0) {
+    auto iterate_rot = [&](auto hd, auto jj, bool& in, uint32_t& steps, const uint32_t d0, const v3 hd_, const v3 ho_) {
         constexpr int H = decltype(hd)::value;
         constexpr uint32_t J = (uint32_t)decltype(jj)::value;
         if (!in) return;
@@ -327,6 +328,24 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
         t += -logf_unit(1.f - rng_to_uniform(rng_xorshift_rot<H>(rng) + (d0 + (2u * J + 1u) * RNG_WEYL))) * s.invSigmaMaxSI;
         if (t > tMax || guard++ >= SVR_WALK_GUARD) { st = END; in = false; steps = 2u * J + 1u; return; }
         if (COUNT) c.taps++;
+        if constexpr (lds_has_bnd8<LDS>::value) {
+            if (fast_bound) {
+                // The bound of the tap's neighbourhood from the ray parameter (svr_accel.hip, k_bound8): a culled draw is a rejection under ANY valid
+                // bound.  (An iteration before the walk's first possibly-occupied cell needs no test of its own: it is culled or fetches a zero opacity,
+                // two draws either way; counting builds keep the test for their prefix counter.)
+                if (COUNT && SKIP && t < t_occ) {
+                    if (!(ray_skippable || tail_counted)) c.ipre++;
+                    rng_xorshift_rot<(H + 1) % 5>(rng);
+                    return;
+                }
+                const uint32_t hx = (uint32_t)fma_(t, hd_.x, ho_.x), hy = (uint32_t)fma_(t, hd_.y, ho_.y), hz = (uint32_t)fma_(t, hd_.z, ho_.z);
+                const uint32_t B = L_.bnd[hx + __umul24(hy, s.hc_sy) + __umul24(hz, s.hc_sz)];
+                const uint32_t x = rng_xorshift_rot<(H + 1) % 5>(rng) + (d0 + (2u * J + 2u) * RNG_WEYL);
+                if ((x >> 24) <= B) { xi = rng_to_uniform(x); st = FETCH; in = false; steps = 2u * J + 2u; }
+                else if (COUNT) c.cull++;
+                return;
+            }
+        }
         if (SKIP && t < t_occ) {
             if (COUNT && !(ray_skippable || tail_counted)) c.ipre++;
             rng_xorshift_rot<(H + 1) % 5>(rng);
@@ -352,11 +371,19 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
         bool in = was;
         uint32_t steps = 10u;
         const uint32_t d0 = rng.d;
-        iterate_rot(RngHead<0>{}, RngHead<0>{}, in, steps, d0);
-        iterate_rot(RngHead<2>{}, RngHead<1>{}, in, steps, d0);
-        iterate_rot(RngHead<4>{}, RngHead<2>{}, in, steps, d0);
-        iterate_rot(RngHead<1>{}, RngHead<3>{}, in, steps, d0);
-        iterate_rot(RngHead<3>{}, RngHead<4>{}, in, steps, d0);
+        // the ray in half-resolution macro-grid coordinates (the fast bound look-up: one fma per axis and iteration)
+        v3 hd_ = dir, ho_ = orig;
+        if constexpr (lds_has_bnd8<LDS>::value) {
+            if (fast_bound) {
+                hd_ = V3(dir.x * s.hc_scale[0], dir.y * s.hc_scale[1], dir.z * s.hc_scale[2]);
+                ho_ = V3(fma_(orig.x - s.vmin[0], s.hc_scale[0], s.hc_off), fma_(orig.y - s.vmin[1], s.hc_scale[1], s.hc_off), fma_(orig.z - s.vmin[2], s.hc_scale[2], s.hc_off));
+            }
+        }
+        iterate_rot(RngHead<0>{}, RngHead<0>{}, in, steps, d0, hd_, ho_);
+        iterate_rot(RngHead<2>{}, RngHead<1>{}, in, steps, d0, hd_, ho_);
+        iterate_rot(RngHead<4>{}, RngHead<2>{}, in, steps, d0, hd_, ho_);
+        iterate_rot(RngHead<1>{}, RngHead<3>{}, in, steps, d0, hd_, ho_);
+        iterate_rot(RngHead<3>{}, RngHead<4>{}, in, steps, d0, hd_, ho_);
         if (was) {
             rng.d = d0 + steps * RNG_WEYL;
             rng_canon(rng, steps >= 10u ? 0u : (steps >= 5u ? steps - 5u : steps));

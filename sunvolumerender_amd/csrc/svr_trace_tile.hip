@@ -185,7 +185,7 @@ __global__ __launch_bounds__(SVR_TILE_THREADS, SVR_TILE_WAVES_PER_EU) void k_tra
 {
     static_assert(!POOL || (QUEUE && SKIP), "the pool form exists for skipping builds with the queue machine");
     static_assert(!DIRECT || QUEUE, "the straight-line builds write their scratch slots anyway");
-    using LDS = typename std::conditional<SKIP, LdsTileCull, LdsTileNoMask>::type;
+    using LDS = typename std::conditional<SKIP, typename std::conditional<POOL, LdsTilePool, LdsTileCull>::type, LdsTileNoMask>::type;
     __shared__ LDS lds;
     __shared__ GroupMapShared gmaps[TILE_WAVES][GROUP_MAPS_PER_WAVE];
     __shared__ typename std::conditional<QUEUE, LdsPendQueue, LdsPend>::type pend;

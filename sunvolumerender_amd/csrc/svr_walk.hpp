@@ -3,6 +3,7 @@
 // tex3D (cell + fetch), the conservative whole-ray march, and the walk loop itself.
 #pragma once
 #include "svr_kernel_common.hpp"
+#include <type_traits>
 
 namespace svr {
 
@@ -23,8 +24,12 @@ struct LdsTileCull : LdsTile {
     uint32_t cls[DIST_WORDS_MAX];              // 4 bits per half-resolution macro-cell
     float thr[BOUND_CLASSES];                  // class -> threshold on the accept draw
 };
-template <typename LDS> struct lds_has_cull { static constexpr bool value = false; };
-template <> struct lds_has_cull<LdsTileCull> { static constexpr bool value = true; };
+// LdsTileCull + the byte table of the fast bound look-up (svr_accel.hip, k_bound8): the POOL builds of the tile kernel
+struct LdsTilePool : LdsTileCull {
+    uint8_t bnd[BOUND8_BYTES];                 // half-resolution macro-cell -> fetch iff (random word >> 24) <= byte
+};
+template <typename LDS> struct lds_has_cull { static constexpr bool value = std::is_base_of<LdsTileCull, LDS>::value; };
+template <typename LDS> struct lds_has_bnd8 { static constexpr bool value = std::is_base_of<LdsTilePool, LDS>::value; };
 
 template <typename LDS>
 SVR_DEV void lds_tile_load(LDS& L, const DevScene& s, bool with_mask)
@@ -49,6 +54,13 @@ SVR_DEV void lds_tile_load(LDS& L, const DevScene& s, bool with_mask)
             uint4* dst3 = reinterpret_cast<uint4*>(L.cls);
             for (uint32_t q = threadIdx.x; q < (s.dist_words + 3u) / 4u; q += blockDim.x) dst3[q] = src3[q];
             if (threadIdx.x < BOUND_CLASSES) L.thr[threadIdx.x] = reinterpret_cast<const float*>(s.empty_mask + ACCEL_THR_OFF)[threadIdx.x];
+        }
+        if constexpr (lds_has_bnd8<LDS>::value) {
+            if (s.bnd8 != nullptr) {
+                const uint4* src4 = reinterpret_cast<const uint4*>(s.bnd8);
+                uint4* dst4 = reinterpret_cast<uint4*>(L.bnd);
+                for (uint32_t q = threadIdx.x; q < BOUND8_BYTES / 16u; q += blockDim.x) dst4[q] = src4[q];
+            }
         }
     }
     __syncthreads();

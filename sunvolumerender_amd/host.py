@@ -213,6 +213,9 @@ class Device:
     def set_option(self, key: int, value: int):
         self.check(self.lib.svr_set_option(int(key), int(value)))
 
+    def get_option(self, key: int) -> int:
+        return int(self.lib.svr_get_option(int(key)))
+
     def counters(self) -> dict:
         c = abi.Counters()
         self.check(self.lib.svr_get_counters(C.byref(c)))

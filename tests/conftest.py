@@ -39,7 +39,7 @@ def _reset_library_options():
         for key, val in ((abi.OPT_ENV_ON_ESCAPE, 0), (abi.OPT_KERNEL, abi.KERNEL_AUTO), (abi.OPT_COUNT, 0), (abi.OPT_EMPTY_SKIP, 1),
                          (abi.OPT_RAY_SKIP, 1), (abi.OPT_PIPELINE, 1), (abi.OPT_FRAME_AHEAD, 1), (abi.OPT_SKIP_TONEMAP, 0),
                          (abi.OPT_FRAMES_PER_WAVE_LOG2, -1), (abi.OPT_RAYCAST_LANES_LOG2, 3), (abi.OPT_FAST_MATH, 0), (abi.OPT_QUEUE, 1),
-                         (abi.OPT_FOLD, 1), (abi.OPT_BOUND_CULL, 1), (abi.OPT_PARK_END, 32), (abi.OPT_GROUP_FRAMES, 64), (abi.OPT_LOCAL_MAJORANT, 0), (abi.OPT_LIGHT_CULL, 1), (abi.OPT_LM_TUNE, 0), (abi.OPT_LM_SUBCELLS, 1), (abi.OPT_PARK_CHEAP, 16), (abi.OPT_PINHOLE_FAST, 1), (abi.OPT_POOL, 1), (abi.OPT_TRIPS, 1), (abi.OPT_NAN_GUARD, 0), (abi.OPT_MACRO_SHIFT_MIN, 0), (abi.OPT_SPLIT, 0), (abi.OPT_ENV_NEE, 0)):
+                         (abi.OPT_FOLD, 1), (abi.OPT_BOUND_CULL, 1), (abi.OPT_PARK_END, 32), (abi.OPT_GROUP_FRAMES, 64), (abi.OPT_LOCAL_MAJORANT, 0), (abi.OPT_LIGHT_CULL, 1), (abi.OPT_LM_TUNE, 0), (abi.OPT_LM_SUBCELLS, 1), (abi.OPT_PARK_CHEAP, 16), (abi.OPT_PINHOLE_FAST, 1), (abi.OPT_POOL, 1), (abi.OPT_TRIPS, 1), (abi.OPT_NAN_GUARD, 0), (abi.OPT_MACRO_SHIFT_MIN, 0), (abi.OPT_SPLIT, 0), (abi.OPT_ENV_NEE, 0), (abi.OPT_FAST_BOUND, 1)):
             dev.lib.svr_set_option(key, val)
         dev.lib.svr_clear_error()
 

@@ -401,6 +401,66 @@ def test_five_iteration_trips_bit_exact(hip_dev, name, depth):
         hip_dev.set_option(abi.OPT_QUEUE, 1)
 
 
+def _odd_noisy_scene(depth=1):
+    """tiny_head_noisy's medium (nothing exactly transparent) as a non-cubic crop with anisotropic spacing, an off-axis thin-lens camera, a
+    density scale and clip planes: every axis of the fast bound look-up gets its own scale, offset and clamp."""
+    base = scenes.make_scene("tiny_head_noisy", trace_depth=depth)
+    vox = np.ascontiguousarray(scenes.make_ct_head_volume(64, noisy_air=True)[6:47, 3:62, 10:55])           # nz=41, ny=59, nx=45
+    spacing = (1.0, 0.5, 2.0)
+    W, H = 50, 37
+    cam = host.camera_setup((30.0, 22.0, 95.0), (1.0, -2.0, 0.5), (0.1, 1.0, 0.0), 40.0, 0.8, 1.3, 1.5, W, H)
+    return dataclasses.replace(base, name="odd_noisy", vox=vox, spacing=spacing, max_magnitude=scenes.max_gradient_magnitude(vox, spacing), width=W, height=H,
+                               camera=cam, density_scale=1.2, clip=((-0.9, 1.0), (-1.0, 0.85), (-0.7, 1.0)))
+
+
+@pytest.mark.parametrize("name,depth", [("tiny_head_noisy", 1), ("tiny_head_noisy", 3), ("small_head_noisy", 1), ("odd_noisy", 1), ("odd_noisy", 2)])
+def test_fast_bound_lookup_bit_exact(hip_dev, name, depth):
+    """SVR_OPT_FAST_BOUND (default on; media without exactly transparent space): the trips of the pooled lane machine take an iteration's fetch
+    bound from one fma per axis on the ray parameter and a byte table whose cells cover one more voxel per side (svr_accel.hip, k_bound8), and
+    compare it with the top 8 bits of the accept draw's random word.  Any valid bound culls correctly: the oracle's accumulator, image and
+    algorithmic counters with the switch on and off -- while the EXECUTED fetches differ (the table is not the class table: it ran)."""
+    sc = _odd_noisy_scene(depth) if name == "odd_noisy" else scenes.make_scene(name, trace_depth=depth)
+    executed = {}
+    try:
+        for nframes in (40, 64):
+            ref_hdr, ref_img, ref_c = oracle_frames(sc, nframes)
+            for fast in (1, 0):
+                hip_dev.set_option(abi.OPT_FAST_BOUND, fast)
+                assert hip_dev.get_option(abi.OPT_FAST_BOUND) == fast
+                hdr, img, c = hip_frames(hip_dev, sc, nframes, batch=True)
+                assert_bit_exact(hdr, ref_hdr, f"{name} depth {depth}: fast bound look-up = {fast}, {nframes} frames")
+                assert np.array_equal(img, ref_img)
+                assert c["vol_taps"] == ref_c["vol_taps"] and c["woodcock_iters"] == ref_c["woodcock_iters"] and c["scatter_events"] == ref_c["scatter_events"]
+                executed[(nframes, fast)] = c["vol_taps_executed"]
+            assert executed[(nframes, 1)] != executed[(nframes, 0)], "the fast bound look-up fetched exactly what the class table does: did it run?"
+            assert executed[(nframes, 1)] < ref_c["vol_taps"]
+    finally:
+        hip_dev.set_option(abi.OPT_FAST_BOUND, 1)
+
+
+def test_fast_bound_lookup_far_camera_falls_back(hip_dev):
+    """The look-up's table covers one voxel of rounding error between its fma and the reference's float chain, which holds while the camera is
+    within 2^21 / (16 N) volume extents (svr_api.hip, ensure_mask); beyond, the kernel takes the exact cell again.  A camera 4 000 extents
+    away looking at the volume through a very long lens: the oracle's image, and the executed fetches of the switch off."""
+    base = scenes.make_scene("tiny_head_noisy", trace_depth=1)
+    ext = max(host.volume_size(base.dim, base.spacing))
+    cam = host.camera_setup((0.0, 0.0, 4000.0 * ext), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.02, 0.0, 1.0, 1.0, base.width, base.height)
+    sc = dataclasses.replace(base, camera=cam)
+    ref_hdr, ref_img, ref_c = oracle_frames(sc, 8)
+    assert ref_c["scatter_events"] > 0
+    executed = []
+    try:
+        for fast in (1, 0):
+            hip_dev.set_option(abi.OPT_FAST_BOUND, fast)
+            hdr, img, c = hip_frames(hip_dev, sc, 8, batch=True)
+            assert_bit_exact(hdr, ref_hdr, f"camera 4 000 extents away, fast bound look-up = {fast}")
+            assert np.array_equal(img, ref_img)
+            executed.append(c["vol_taps_executed"])
+        assert executed[0] == executed[1]
+    finally:
+        hip_dev.set_option(abi.OPT_FAST_BOUND, 1)
+
+
 def test_pinhole_camera_fast_path(hip_dev):
     """With apeture == 0 (the reference's default) the lens sample is (+-0, +-0) and camera_ray skips its square root and sine / cosine
     (SVR_OPT_PINHOLE_FAST): the oracle's image bit for bit with the switch on and off, with a camera position that holds a -0 component

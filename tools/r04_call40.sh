@@ -1,4 +1,9 @@
 set -e
 cd $GRAFT_REPO_ROOT
-L=$GRAFT_REPO_ROOT/sunvolumerender_amd/lib
-for v in "" _nb6 _nb8 _nb12 _nb14 ""; do echo "== lib$v" | tee -a gpurun_out/r04J.log; for sc in c5 c3; do SVR_HIP_LIB=$L/libsvr_hip$v.so timeout -k 10 300 python tools/sweep.py --scene $sc --frames 256 --spp 256 lm=1 2>&1 | tee -a gpurun_out/r04J.log; done; done
+LOG=gpurun_out/r04E_fast_bound.log
+timeout -k 10 900 python -m pytest tests/test_more_gpu.py -x -q -m gpu -k "fast_bound or trips or pooled" 2>&1 | tail -5 | tee -a $LOG
+timeout -k 10 600 python -m pytest tests/test_configs_gpu.py -x -q -m gpu -k "c3n" 2>&1 | tail -5 | tee -a $LOG
+timeout -k 10 300 python tools/sweep.py --scene c3n --depth 1 --frames 256 --spp 256 fast_bound=1 fast_bound=0 fast_bound=1 fast_bound=0 2>&1 | tee -a $LOG
+timeout -k 10 300 python tools/sweep.py --scene c3n --depth 1 --frames 64 --spp 64 --count fast_bound=1 fast_bound=0 2>&1 | tee -a $LOG
+timeout -k 10 300 python tools/sweep.py --scene c3n --depth 2 --frames 128 --spp 128 fast_bound=1 fast_bound=0 2>&1 | tee -a $LOG
+timeout -k 10 300 python tools/sweep.py --scene c3n --depth 4 --frames 128 --spp 128 fast_bound=1 fast_bound=0 2>&1 | tee -a $LOG

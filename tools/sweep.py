@@ -12,7 +12,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from sunvolumerender_amd import abi, host, scenes  # noqa: E402
 
 KEYS = {"bound_cull": abi.OPT_BOUND_CULL, "empty_skip": abi.OPT_EMPTY_SKIP, "ray_skip": abi.OPT_RAY_SKIP,
-        "fl2": abi.OPT_FRAMES_PER_WAVE_LOG2, "kernel": abi.OPT_KERNEL, "frame_ahead": abi.OPT_FRAME_AHEAD, "fast_math": abi.OPT_FAST_MATH, "fold": abi.OPT_FOLD, "queue": abi.OPT_QUEUE, "park_end": abi.OPT_PARK_END, "fine_mask": abi.OPT_FINE_MASK, "row_order": abi.OPT_ROW_ORDER, "group": abi.OPT_GROUP_FRAMES, "lm": abi.OPT_LOCAL_MAJORANT, "lm_tune": abi.OPT_LM_TUNE, "light_cull": abi.OPT_LIGHT_CULL, "lm_sub": abi.OPT_LM_SUBCELLS, "park_cheap": abi.OPT_PARK_CHEAP, "pinhole_fast": abi.OPT_PINHOLE_FAST, "pool": abi.OPT_POOL, "trips": abi.OPT_TRIPS, "split": abi.OPT_SPLIT, "nan_guard": abi.OPT_NAN_GUARD, "env_nee": abi.OPT_ENV_NEE}
+        "fl2": abi.OPT_FRAMES_PER_WAVE_LOG2, "kernel": abi.OPT_KERNEL, "frame_ahead": abi.OPT_FRAME_AHEAD, "fast_math": abi.OPT_FAST_MATH, "fold": abi.OPT_FOLD, "queue": abi.OPT_QUEUE, "park_end": abi.OPT_PARK_END, "fine_mask": abi.OPT_FINE_MASK, "row_order": abi.OPT_ROW_ORDER, "group": abi.OPT_GROUP_FRAMES, "lm": abi.OPT_LOCAL_MAJORANT, "lm_tune": abi.OPT_LM_TUNE, "light_cull": abi.OPT_LIGHT_CULL, "lm_sub": abi.OPT_LM_SUBCELLS, "park_cheap": abi.OPT_PARK_CHEAP, "pinhole_fast": abi.OPT_PINHOLE_FAST, "pool": abi.OPT_POOL, "trips": abi.OPT_TRIPS, "split": abi.OPT_SPLIT, "nan_guard": abi.OPT_NAN_GUARD, "env_nee": abi.OPT_ENV_NEE, "fast_bound": abi.OPT_FAST_BOUND}
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="c3")
 ap.add_argument("--depth", type=int, default=1)
