@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_bound8(const uint16_t* __restrict__ mmw
 {
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
     if (e >= BOUND8_BYTES) return;
-    const uint32_t px = (uint32_t)hgx + 2u, py = (uint32_t)hgy + 2u, pz = (uint32_t)hgz + 2u;
+    const uint32_t px = BOUND8_DIM, py = BOUND8_DIM, pz = BOUND8_DIM;
     if (e >= px * py * pz) { bnd8[e] = 255u; return; }
     // entry (x + 1, y + 1, z + 1) = cell (x, y, z); the entries around the grid repeat its edge cells
     const int x = min(max((int)(e % px) - 1, 0), hgx - 1), y = min(max((int)((e / px) % py) - 1, 0), hgy - 1), z = min(max((int)(e / (px * py)) - 1, 0), hgz - 1);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_bound8(const uint16_t* __restrict__ mmw
 hipError_t launch_bound8(const uint16_t* mm_wide, int hgx, int hgy, int hgz, const float* tf_rgba, int tf_n, float densityScale,
                          float invSigmaMax, uint8_t* bnd8, hipStream_t st)
 {
-    if ((uint64_t)(hgx + 2) * (uint64_t)(hgy + 2) * (uint64_t)(hgz + 2) > BOUND8_BYTES) return hipErrorInvalidValue;
+    if (hgx + 2 > (int)BOUND8_DIM || hgy + 2 > (int)BOUND8_DIM || hgz + 2 > (int)BOUND8_DIM) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_bound8, dim3(BOUND8_BYTES / 256u), dim3(256), 0, st, mm_wide, hgx, hgy, hgz, tf_rgba, tf_n, densityScale, invSigmaMax, bnd8);
     return hipGetLastError();
 }

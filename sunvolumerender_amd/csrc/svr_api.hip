@@ -571,7 +571,6 @@ int ensure_mask(svr::DevScene& s, const svr_volume& vol, const svr_transfer_func
     s.bnd8 = nullptr;
     s.hc_scale[0] = 0.5f * s.mc_scale[0]; s.hc_scale[1] = 0.5f * s.mc_scale[1]; s.hc_scale[2] = 0.5f * s.mc_scale[2];
     s.hc_off = 0.5f * s.mc_off + 1.f;
-    s.hc_sy = (uint32_t)((tv->mc_gx + 1) / 2 + 2); s.hc_sz = s.hc_sy * (uint32_t)((tv->mc_gy + 1) / 2 + 2);
     if (g.opt_fast_bound && g.bnd8_valid && s.bound_cull && !s.has_empty && s.fine_mask == nullptr && s.trips && inside) {
         bool near_enough = true;
         const int nmax = tv->nx > tv->ny ? (tv->nx > tv->nz ? tv->nx : tv->nz) : (tv->ny > tv->nz ? tv->ny : tv->nz);

@@ -90,9 +90,11 @@ hipError_t launch_bound_class(const uint16_t* mm, int gx, int gy, int gz, const 
                               float invSigmaMax, uint32_t* accel, hipStream_t stream);
 // fast bound look-up of the lane machine (svr_lanes.hpp, iterate_rot): one byte per half-resolution macro-cell from the WIDE min/max table
 // (footprints grown by one voxel: launch_minmax with shift + 1, pad 1) -- a fetch is needed only if (accept draw's random word >> 24) <= byte.
-// The table has one more cell on EVERY side of the grid (copies of the edge cells; rows of hgx + 2, slices of (hgx + 2)(hgy + 2)), so the
-// look-up needs no clamp: cell (x, y, z) of the grid is entry (x + 1, y + 1, z + 1).
-constexpr uint32_t BOUND8_BYTES = 40960u;          // >= 34^3: up to 32^3 half-resolution cells
+// The table has one more cell on EVERY side of the grid (copies of the edge cells), so the look-up needs no clamp: cell (x, y, z) of the grid is
+// entry (x + 1, y + 1, z + 1) of a table with FIXED rows of BOUND8_DIM entries and slices of BOUND8_DIM^2 (the grid has at most 32 cells per axis; 34
+// is an inline constant of the two multiply-adds that form the index).
+constexpr uint32_t BOUND8_DIM = 34u;
+constexpr uint32_t BOUND8_BYTES = 40960u;          // >= 34^3
 hipError_t launch_bound8(const uint16_t* mm_wide, int hgx, int hgy, int hgz, const float* tf_rgba, int tf_n, float densityScale,
                          float invSigmaMax, uint8_t* bnd8, hipStream_t stream);
 // rows of one rank of a row-strip shard: packed (n_rows x row_floats) <-> full frame; to_packed: 1 = pack, 0 = unpack

@@ -339,7 +339,12 @@ SVR_DEV void drain_queue(const DevScene& s, const LDS& L_, const LaneQueue& Q, u
                     return;
                 }
                 const uint32_t hx = (uint32_t)fma_(t, hd_.x, ho_.x), hy = (uint32_t)fma_(t, hd_.y, ho_.y), hz = (uint32_t)fma_(t, hd_.z, ho_.z);
-                const uint32_t B = L_.bnd[hx + __umul24(hy, s.hc_sy) + __umul24(hz, s.hc_sz)];
+                // (hz * 34 + hy) * 34 + hx as two 24-bit multiply-adds with the inline constant (the compiler makes the first a 64-bit v_mad_u64_u32)
+                static_assert(BOUND8_DIM == 34u, "the inline constant of the index");
+                uint32_t zy, e;
+                asm("v_mad_u32_u24 %0, %1, 34, %2" : "=v"(zy) : "v"(hz), "v"(hy));
+                asm("v_mad_u32_u24 %0, %1, 34, %2" : "=v"(e) : "v"(zy), "v"(hx));
+                const uint32_t B = L_.bnd[e];
                 const uint32_t x = rng_xorshift_rot<(H + 1) % 5>(rng) + (d0 + (2u * J + 2u) * RNG_WEYL);
                 if ((x >> 24) <= B) { xi = rng_to_uniform(x); st = FETCH; in = false; steps = 2u * J + 2u; }
                 else if (COUNT) c.cull++;

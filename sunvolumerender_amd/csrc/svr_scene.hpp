@@ -87,11 +87,10 @@ struct DevScene {
     const float* env_cdf;
     // (appended) fast bound look-up of the lane machine's POOL builds (svr_accel.hip, k_bound8; svr_lanes.hpp, iterate_rot): the byte table (BOUND8_BYTES, global
     // memory; the kernel keeps it in LDS) or null = not used, and the table coordinate of a world point, (p - vmin) * hc_scale + hc_off (half-resolution
-    // macro-grid coordinate + 1: the table has one more cell around the grid), rows of hc_sy and slices of hc_sz entries
+    // macro-grid coordinate + 1: the table has one more cell around the grid)
     const uint8_t* bnd8;
     float hc_scale[3];
     float hc_off;
-    uint32_t hc_sy, hc_sz;
 };
 
 // per-launch work description.  Tracing and accumulation are decoupled: the trace kernel writes the

@@ -24,10 +24,13 @@ struct LdsTileCull : LdsTile {
     uint32_t cls[DIST_WORDS_MAX];              // 4 bits per half-resolution macro-cell
     float thr[BOUND_CLASSES];                  // class -> threshold on the accept draw
 };
-// LdsTileCull + the byte table of the fast bound look-up (svr_accel.hip, k_bound8): the POOL builds of the tile kernel
-struct LdsTilePool : LdsTileCull {
+// LdsTileCull + the byte table of the fast bound look-up (svr_accel.hip, k_bound8): the POOL builds of the tile kernel.  The table comes FIRST:
+// the object sits at LDS address 0, so the index is the address (no base to add in the walk loop; the other tables' offsets still fit their instructions'
+// 16-bit offset field, except the `empty` bits and the classes, which media that take the fast look-up do not read)
+struct LdsBound8 {
     uint8_t bnd[BOUND8_BYTES];                 // half-resolution macro-cell -> fetch iff (random word >> 24) <= byte
 };
+struct LdsTilePool : LdsBound8, LdsTileCull {};
 template <typename LDS> struct lds_has_cull { static constexpr bool value = std::is_base_of<LdsTileCull, LDS>::value; };
 template <typename LDS> struct lds_has_bnd8 { static constexpr bool value = std::is_base_of<LdsTilePool, LDS>::value; };
 
