@@ -339,6 +339,11 @@ int svr_selftest_chain(const float* items, float* results, uint32_t n);
  * 6 atan2f(y, x)  7 powf(x, y)  8 k-th curand_uniform of curand_init(seed bits, 0, 0): in = (seed bits, k)
  * 9 wangHash(bits) as bits  10 log(1 - u) of the Woodcock walk (logf_unit) */
 int svr_selftest_math(int fn, const float* in, uint32_t in_stride, float* out, uint32_t n);
+/* test hook: property test of SVR_OPT_FAST_BOUND's table on the scene set up as for render_pathtracer.  rays = n x 7 floats (origin, direction, u):
+ * at the point t = tMin + u (tMax - tMin) of the ray's box interval, the byte the lane machine would read against the product the reference's
+ * accept test forms there (exact cell, fetch, alpha, invSigmaMax).  out[i] = 1 tested | 2 VIOLATION (a draw the byte culls could be accepted)
+ * | 4 index outside the table | byte << 8; 0 = the ray misses the box.  Fails (-3) when the look-up is not in use for the scene */
+int svr_selftest_bound8(const float* rays, uint32_t n, uint32_t* out);
 int svr_get_counters(svr_counters* out);              /* synchronises the launch stream */
 int svr_reset_counters(void);
 

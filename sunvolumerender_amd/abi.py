@@ -223,6 +223,7 @@ PROTOTYPES = {
     "svr_hdr_to_ldr_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "svr_selftest_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "svr_selftest_math": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "svr_selftest_bound8": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "svr_get_counters": (C.c_int, [_P(Counters)]),
     "svr_reset_counters": (C.c_int, []),
     "svr_get_kernel_time": (C.c_int, [_P(C.c_double), _P(C.c_uint64)]),

@@ -1705,6 +1705,29 @@ int svr_selftest_math(int fn, const float* in, uint32_t in_stride, float* out, u
     return 0;
 }
 
+// test hook: property test of the fast bound look-up on the CURRENT scene (set up as for render_pathtracer): csrc/svr_selftest.hip
+int svr_selftest_bound8(const float* rays, uint32_t n, uint32_t* out)
+{
+    if (ensure_init()) return g.err_code;
+    if (!rays || !out || n == 0) return fail(-4, "svr_selftest_bound8: bad arguments");
+    if (!g.have_vol || !g.have_tf || !g.have_cam) return fail(-4, "svr_selftest_bound8 before setup_volume/setup_transferfunction/setup_camera");
+    svr::DevScene s;
+    if (build_scene(g.vol, g.tf, g.cam, s)) return g.err_code;
+    if (ensure_mask(s, g.vol, g.tf)) return g.err_code;
+    if (s.bnd8 == nullptr) return fail(-3, "svr_selftest_bound8: the fast bound look-up is not in use for this scene");
+    float* d_rays = nullptr; uint32_t* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rays, (size_t)n * 7 * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_out, (size_t)n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = svr::launch_bound8_selftest(s, d_rays, n, d_out, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    hipFree(d_rays);
+    if (d_out) hipFree(d_out);
+    if (e != hipSuccess) return fail((int)e, "svr_selftest_bound8 failed: %s", hipGetErrorName(e));
+    return 0;
+}
+
 #ifdef SVR_TEST_HOOKS
 // experiment builds: the lane machine's phase profile (svr_lanes.hpp), n <= 32 words, cleared by svr_reset_counters
 extern "C" int svr_debug_phase_profile(uint64_t* out, int n)

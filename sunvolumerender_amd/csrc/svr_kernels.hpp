@@ -106,6 +106,8 @@ hipError_t launch_tonemap(const DevScene& scene, const DevWork& work, hipStream_
 hipError_t launch_chain_selftest(const float4* in, float4* out, uint32_t n, hipStream_t stream);
 // device-side known-answer tests (tests only): out[i] = fn(in[i * in_stride ...]); fn ids in svr_selftest.hip
 hipError_t launch_math_selftest(int fn, const float* in, uint32_t in_stride, float* out, uint32_t n, hipStream_t stream);
+// property test of the fast bound look-up (tests only): rays = n x (origin, direction, u); out = n flag words (svr_selftest.hip)
+hipError_t launch_bound8_selftest(const DevScene& scene, const float* rays, uint32_t n, uint32_t* out, hipStream_t stream);
 // kernel_raycasting over the owned pixels
 hipError_t launch_raycast(const DevScene& scene, const DevWork& work, float stepSize, bool count, int num_cus, int lanes_log2, hipStream_t stream);
 // repack a [nz][ny][nx] u16 volume (device) into the padded LINEAR or BRICK layout (device)

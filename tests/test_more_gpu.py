@@ -438,6 +438,77 @@ def test_fast_bound_lookup_bit_exact(hip_dev, name, depth):
         hip_dev.set_option(abi.OPT_FAST_BOUND, 1)
 
 
+def _bound8_rays(sc, rs, n):
+    """Rays for svr_selftest_bound8: camera rays through random pixels, rays between random points of the volume's box (incl. points ON its faces, edges
+    and corners, and axis-parallel directions), each with u in [0, 1] -- a quarter of them exactly 0 or 1 (the box entry and exit)."""
+    size = np.asarray(host.volume_size(sc.dim, sc.spacing), dtype=np.float64)
+    cam = sc.resolved_camera()
+    eye = np.array([cam.pos.x, cam.pos.y, cam.pos.z], dtype=np.float64)
+    k = n // 4
+    # (a) from the eye towards random points of a slightly larger box (some miss)
+    tgt = (rs.rand(k, 3) - 0.5) * size * 1.1
+    a = np.concatenate([np.broadcast_to(eye, (k, 3)), tgt - eye], axis=1)
+    # (b) between two random interior points
+    p, q = (rs.rand(k, 3) - 0.5) * size, (rs.rand(k, 3) - 0.5) * size
+    b = np.concatenate([p, q - p], axis=1)
+    # (c) from points with some coordinates snapped onto the faces
+    p = (rs.rand(k, 3) - 0.5) * size
+    snap = rs.rand(k, 3) < 0.4
+    p = np.where(snap, np.sign(p) * 0.5 * size, p)
+    q = (rs.rand(k, 3) - 0.5) * size
+    c = np.concatenate([p, q - p], axis=1)
+    # (d) axis-parallel and plane-parallel directions from interior points and from the eye
+    p = (rs.rand(n - 3 * k, 3) - 0.5) * size
+    d = rs.randn(n - 3 * k, 3)
+    d[rs.rand(n - 3 * k, 3) < 0.5] = 0.0
+    d[np.all(d == 0.0, axis=1)] = (0.0, 0.0, 1.0)
+    dd = np.concatenate([p, d], axis=1)
+    rays = np.concatenate([a, b, c, dd], axis=0)
+    nrm = np.linalg.norm(rays[:, 3:6], axis=1, keepdims=True)
+    rays[:, 3:6] /= np.where(nrm > 0, nrm, 1.0)
+    u = rs.rand(n, 1)
+    ends = rs.rand(n, 1)
+    u = np.where(ends < 0.125, 0.0, np.where(ends < 0.25, 1.0, u))
+    return np.ascontiguousarray(np.concatenate([rays, u], axis=1), dtype=np.float32)
+
+
+@pytest.mark.parametrize("name", ["tiny_head_noisy", "small_head_noisy", "odd_noisy", "odd_noisy_bone_fog"])
+def test_fast_bound_table_bounds_every_fetch(hip_dev, name):
+    """The property the bit-exactness of SVR_OPT_FAST_BOUND rests on, tested directly (svr_selftest_bound8, csrc/svr_selftest.hip): at 2 million points of
+    rays through the volume -- camera rays, rays between interior points, from points on the faces, edges and corners, axis-parallel ones, a quarter of the
+    points exactly at the box entry or exit -- the byte the lane machine would read (the same expressions for the ray in table coordinates and the index)
+    culls no draw that the reference's accept test at that point (exact trilinear cell, fetch, alpha, invSigmaMax) could accept, and the index stays
+    inside the table."""
+    if name == "odd_noisy_bone_fog":
+        # a steeper transfer function over the same medium: bounds from 0.01 to 1 within a few cells
+        sc = _odd_noisy_scene(1)
+        tf = np.array(sc.tf_rgba, dtype=np.float32, copy=True)
+        tf[:, 3] = np.maximum(tf[:, 3] ** 3 / max(float(tf[:, 3].max()), 1e-6) ** 2, 1e-3 * float(tf[:, 3].max()))
+        sc = dataclasses.replace(sc, name=name, tf_rgba=tf, max_opacity=float(tf[:, 3].max()))
+    else:
+        sc = _odd_noisy_scene(1) if name == "odd_noisy" else scenes.make_scene(name, trace_depth=1)
+    c = host.Canvas(hip_dev, sc.width, sc.height)
+    try:
+        scenes.apply_to_canvas(sc, c, 0)
+        c.ReStartRender()
+        c.paint()                                        # (the acceleration data is built with the first render)
+        hip_dev.synchronize()
+        rs = np.random.RandomState(11)
+        n = 1 << 21
+        rays = _bound8_rays(sc, rs, n)
+        out = np.zeros(n, dtype=np.uint32)
+        hip_dev.check(hip_dev.lib.svr_selftest_bound8(rays.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)))
+    finally:
+        c.close()
+    tested = (out & 1) != 0
+    assert tested.sum() > n // 2, f"{name}: only {tested.sum()} of {n} rays hit the box"
+    assert not np.any(out & 4), f"{name}: {np.count_nonzero(out & 4)} look-ups outside the table"
+    bad = np.flatnonzero(out & 2)
+    assert bad.size == 0, f"{name}: {bad.size} points where the byte culls a draw the accept test could accept, e.g. ray {rays[bad[0]]} byte {out[bad[0]] >> 8}"
+    byts = (out[tested] >> 8) & 0xff
+    assert byts.min() < 255 and np.unique(byts).size > 4, f"{name}: the table holds no bound to speak of (bytes {np.unique(byts)[:8]})"
+
+
 def test_fast_bound_lookup_far_camera_falls_back(hip_dev):
     """The look-up's table covers one voxel of rounding error between its fma and the reference's float chain, which holds while the camera is
     within 2^21 / (16 N) volume extents (svr_api.hip, ensure_mask); beyond, the kernel takes the exact cell again.  A camera 4 000 extents
