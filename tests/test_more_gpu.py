@@ -647,12 +647,13 @@ def test_frame_ahead_matches_per_frame_calls(hip_dev):
             canvas.close()
 
 
-@pytest.mark.parametrize("name,depth", [("tiny_head", 1), ("tiny_head_noisy", 1), ("tiny_head", 2), ("tiny_bone", 4)])
+@pytest.mark.parametrize("name,depth", [("tiny_head", 1), ("tiny_head_noisy", 1), ("tiny_head", 2), ("tiny_bone", 4), ("tiny_head_noisy", 2)])
 def test_frame_ahead_steady_state_with_a_sync_per_call(hip_dev, name, depth):
     """The reference's host protocol, gui/canvas.cpp:96-116: render_pathtracer, cudaDeviceSynchronize, frameNo++ -- 200 times, i.e. well
     into the steady state of frame-ahead tracing (64-frame batches traced by the queue builds of the tile kernel into scratch slots while
     the previous batch is consumed; svr_device_synchronize waits for the caller's stream only).  The accumulator and the image after
-    frames 100 and 200 are the oracle's, bit for bit; tiny_head_noisy runs the pooled primary walks, depth 2 / 4 the lane machine."""
+    frames 100 and 200 are the oracle's, bit for bit; tiny_head_noisy runs the pooled primary walks with the fast bound look-up (at depth 2: the
+    deeper pooled machine writing scratch slots), depth 2 / 4 the lane machine."""
     sc = scenes.make_scene(name, trace_depth=depth)
     o = binding.OracleScene(sc)
     acc = o.new_hdr()
