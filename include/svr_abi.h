@@ -299,7 +299,7 @@ int svr_assemble_frame(void* nccl_comm, void* frame_on_root, const void* hdr_loc
 #define SVR_OPT_FAST_BOUND 35       /* default 1: media without exactly transparent space (walks of tens of iterations under bound culling: the pooled lane machine of the tile
                                      * kernel) look the fetch bound of an iteration up from the ray parameter -- one fma per axis into a byte table whose cells cover one more
                                      * voxel per side, compared with the top 8 bits of the accept draw's random word (csrc/svr_accel.hip k_bound8) -- instead of from the exact
-                                     * trilinear cell and a class threshold.  Any valid bound culls correctly: results unchanged (bit-exact); c3n +15 %, c3n at depth 2 / 4 +30 % / +22 %.  Needs the clipped box inside the volume and the camera within 2^21 / (16 N) volume extents (else, and with 0: the exact cell) */
+                                     * trilinear cell and a class threshold.  Any valid bound culls correctly: results unchanged (bit-exact); c3n +17 %, c3n at depth 2 / 4 +32 % / +31 % (same box).  Needs the clipped box inside the volume and the camera within 2^21 / (16 N) volume extents (else, and with 0: the exact cell) */
 #define SVR_OPT_FRAME_AHEAD 13           /* render_pathtracer traces frames ahead of the calls that ask for them (batches of 1, 2, 4 ... 32 frames; results unchanged); default 1 */
 #define SVR_OPT_RAYCAST_LANES_LOG2 12   /* ray caster: 1 << v adjacent lanes share one ray (samples of a chunk in parallel, composited in order); 0..5, default 3 */
 #define SVR_OPT_FRAMES_PER_WAVE_LOG2 11 /* tile kernel: a wave traces (64 >> f) pixels x (1 << f) frames of a group; -1 (default) = up to 8 frames */
